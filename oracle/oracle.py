@@ -1,0 +1,289 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg -- never by the orb_slam2_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liborb_oracle.so")
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")]
+)
+WQUERY_DTYPE = np.dtype(
+    [("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("minLevel", "<i4"), ("maxLevel", "<i4"),
+     ("angle", "<f4"), ("ur", "<f4"), ("flags", "<i4")]
+)
+assert KEYPOINT_DTYPE.itemsize == 28 and WQUERY_DTYPE.itemsize == 32
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scaleFactor", C.c_float), ("nlevels", C.c_int),
+                ("iniThFAST", C.c_int), ("minThFAST", C.c_int), ("gauss_variant", C.c_int)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "orb_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_cvround_f.argtypes = [C.c_float]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_extractor_create.restype = C.c_void_p
+        L.orc_extractor_create.argtypes = [C.POINTER(Params)]
+        L.orc_extractor_destroy.argtypes = [C.c_void_p]
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_int]
+        L.orc_extractor_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_extractor_level_count.argtypes = [C.c_void_p, C.c_int]
+        L.orc_extractor_tie_straddles.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_params(nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, gauss_variant=0):
+    return Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, gauss_variant)
+
+
+def tables(p):
+    L = p.nlevels
+    sc = np.zeros(L, np.float32); inv = np.zeros(L, np.float32)
+    s2 = np.zeros(L, np.float32); is2 = np.zeros(L, np.float32)
+    quota = np.zeros(L, np.int32); umax = np.zeros(16, np.int32)
+    rc = lib().orc_tables(C.byref(p), _p(sc), _p(inv), _p(s2), _p(is2), _p(quota), _p(umax))
+    assert rc == 0
+    return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
+
+
+def level_size(p, w, h, level):
+    lw, lh = C.c_int(), C.c_int()
+    lib().orc_level_size(C.byref(p), w, h, level, C.byref(lw), C.byref(lh))
+    return lw.value, lh.value
+
+
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_hamming256(_p(a), _p(b))
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    rc = lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    assert rc == 0
+    return dst
+
+
+def border101(img, border=19):
+    h, w = img.shape
+    buf = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    buf[border:border + h, border:border + w] = img
+    inner = buf[border:, border:]
+    lib().orc_border_reflect101(C.c_void_p(inner.ctypes.data), w, h, buf.strides[0], border)
+    return buf
+
+
+def gauss7(img, variant=0):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    dst = np.zeros_like(img)
+    lib().orc_gauss7(_p(img), w, h, img.strides[0], _p(dst), w, variant)
+    return dst
+
+
+def fast9(img, threshold, nonmax=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h
+    xs = np.zeros(cap, np.int32); ys = np.zeros(cap, np.int32); sc = np.zeros(cap, np.int32)
+    n = lib().orc_fast9(_p(img), w, h, img.strides[0], threshold, int(nonmax), _p(xs), _p(ys), _p(sc), cap)
+    assert n >= 0
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def fast_score_map(img):
+    """Threshold-free score (A-1 clamped at 0) for every pixel with a 3 px margin."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.int32)
+    f = lib().orc_fast_score_pixel
+    base = img.ctypes.data
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            out[y, x] = f(C.c_void_p(base + y * img.strides[0] + x), img.strides[0])
+    return out
+
+
+def level_candidates(plane, iniTh=20, minTh=7):
+    plane = np.ascontiguousarray(plane, np.uint8)
+    h, w = plane.shape
+    cap = w * h // 4 + 1024
+    xs = np.zeros(cap, np.float32); ys = np.zeros(cap, np.float32); rs = np.zeros(cap, np.float32)
+    n = lib().orc_level_candidates(_p(plane), w, h, plane.strides[0], iniTh, minTh, _p(xs), _p(ys), _p(rs), cap)
+    assert 0 <= n <= cap, n
+    return xs[:n].copy(), ys[:n].copy(), rs[:n].copy()
+
+
+def distribute_octree(xs, ys, resp, minX, maxX, minY, maxY, N):
+    xs = np.ascontiguousarray(xs, np.float32); ys = np.ascontiguousarray(ys, np.float32)
+    resp = np.ascontiguousarray(resp, np.float32)
+    n = len(xs)
+    cap = N + 4 * 16 + 64
+    out = np.zeros(cap, np.int32)
+    ts = C.c_int(0)
+    m = lib().orc_distribute_octree(_p(xs), _p(ys), _p(resp), n, minX, maxX, minY, maxY, N, _p(out), cap, C.byref(ts))
+    assert 0 <= m <= cap, m
+    return out[:m].copy(), ts.value
+
+
+def ic_angle(plane, cx, cy, umax):
+    plane = np.ascontiguousarray(plane, np.uint8)
+    umax = np.ascontiguousarray(umax, np.int32)
+    return float(lib().orc_ic_angle(_p(plane), plane.strides[0], cx, cy, _p(umax)))
+
+
+def brief(blurred, cx, cy, angle_deg):
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orc_brief(_p(blurred), blurred.strides[0], cx, cy, C.c_float(angle_deg), _p(d))
+    return d
+
+
+class Extractor:
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, gauss_variant=0):
+        self.p = make_params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, gauss_variant)
+        self.h = lib().orc_extractor_create(C.byref(self.p))
+        assert self.h
+        self.cap = nfeatures + 64 * nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_extractor_destroy(self.h)
+            self.h = None
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        kps = np.zeros(self.cap, KEYPOINT_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = lib().orc_extract(self.h, _p(img), w, h, img.strides[0], _p(kps), _p(desc), self.cap)
+        assert 0 <= n <= self.cap, n
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level(self, level, blurred=False):
+        ptr = C.c_void_p(); w = C.c_int(); h = C.c_int(); st = C.c_int()
+        rc = lib().orc_extractor_level(self.h, level, int(blurred), C.byref(ptr), C.byref(w), C.byref(h), C.byref(st))
+        if rc != 0:
+            return None
+        buf = (C.c_uint8 * (st.value * (h.value - 1) + w.value)).from_address(ptr.value)
+        arr = np.frombuffer(buf, np.uint8)
+        out = np.zeros((h.value, w.value), np.uint8)
+        for y in range(h.value):
+            out[y] = arr[y * st.value:y * st.value + w.value]
+        return out
+
+    def level_count(self, level):
+        return lib().orc_extractor_level_count(self.h, level)
+
+    def tie_straddles(self):
+        return lib().orc_extractor_tie_straddles(self.h)
+
+
+def bruteforce(Q, T):
+    Q = np.ascontiguousarray(Q, np.uint8); T = np.ascontiguousarray(T, np.uint8)
+    nq, nt = len(Q), len(T)
+    bi = np.zeros(nq, np.int32); b1 = np.zeros(nq, np.int32); b2 = np.zeros(nq, np.int32)
+    lib().orc_bruteforce(_p(Q), nq, _p(T), nt, _p(bi), _p(b1), _p(b2))
+    return bi, b1, b2
+
+
+def grid_build(kps, bounds):
+    kps = np.ascontiguousarray(kps); b = np.asarray(bounds, np.float32)
+    cs = np.zeros(64 * 48 + 1, np.int32); ci = np.zeros(max(len(kps), 1), np.int32)
+    lib().orc_grid_build(_p(kps), len(kps), _p(b), _p(cs), _p(ci))
+    return cs, ci[:cs[-1]].copy()
+
+
+def features_in_area(kps, bounds, cs, ci, x, y, r, minLevel=-1, maxLevel=-1):
+    kps = np.ascontiguousarray(kps); b = np.asarray(bounds, np.float32)
+    ci = np.ascontiguousarray(ci, np.int32) if len(ci) else np.zeros(1, np.int32)
+    out = np.zeros(max(len(kps), 1), np.int32)
+    n = lib().orc_features_in_area(_p(kps), _p(b), _p(cs), _p(ci), C.c_float(x), C.c_float(y), C.c_float(r),
+                                   minLevel, maxLevel, _p(out), len(out))
+    return out[:n].copy()
+
+
+def three_maxima(sizes):
+    s = np.ascontiguousarray(sizes, np.int32)
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    lib().orc_three_maxima(_p(s), len(s), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_xy, windowSize=100, nnratio=0.9, checkOri=True):
+    kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    b = np.asarray(bounds, np.float32)
+    prev = np.ascontiguousarray(prev_xy, np.float32).copy()
+    m12 = np.zeros(max(len(kps1), 1), np.int32)
+    n = lib().orc_search_for_initialization(_p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2), _p(b),
+                                            _p(prev), _p(m12), windowSize, C.c_float(nnratio), int(checkOri))
+    return n, m12[:len(kps1)].copy(), prev
+
+
+def search_by_projection(mode, queries, qdesc, kps2, desc2, bounds, uright2=None, occupied=None, th_dist=100,
+                         nnratio=0.8, checkOri=True):
+    q = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    kps2 = np.ascontiguousarray(kps2); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    b = np.asarray(bounds, np.float32)
+    ur = None if uright2 is None else np.ascontiguousarray(uright2, np.float32)
+    oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    assign = np.zeros(max(len(kps2), 1), np.int32)
+    n = lib().orc_search_by_projection(mode, _p(q), _p(qdesc), len(q), _p(kps2), _p(desc2), _p(ur), len(kps2), _p(b),
+                                       _p(oc), _p(assign), th_dist, C.c_float(nnratio), int(checkOri))
+    return n, assign[:len(kps2)].copy()
+
+
+def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, bf, b):
+    """pyrL/pyrR: lists of contiguous 2-D uint8 level planes."""
+    kpsL = np.ascontiguousarray(kpsL); kpsR = np.ascontiguousarray(kpsR)
+    descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
+    nl = len(pyrL)
+    pl = [np.ascontiguousarray(a, np.uint8) for a in pyrL]
+    pr = [np.ascontiguousarray(a, np.uint8) for a in pyrR]
+    PL = (C.c_void_p * nl)(*[a.ctypes.data for a in pl])
+    PR = (C.c_void_p * nl)(*[a.ctypes.data for a in pr])
+    ws = np.array([a.shape[1] for a in pl], np.int32); hs = np.array([a.shape[0] for a in pl], np.int32)
+    sL = np.array([a.strides[0] for a in pl], np.int32); sR = np.array([a.strides[0] for a in pr], np.int32)
+    sc = np.ascontiguousarray(scale, np.float32); isc = np.ascontiguousarray(inv_scale, np.float32)
+    uR = np.zeros(max(len(kpsL), 1), np.float32); dep = np.zeros(max(len(kpsL), 1), np.float32)
+    n = lib().orc_stereo_matches(_p(kpsL), _p(descL), len(kpsL), _p(kpsR), _p(descR), len(kpsR), PL, PR, _p(ws), _p(hs),
+                                 _p(sL), _p(sR), nl, _p(sc), _p(isc), C.c_float(bf), C.c_float(b), _p(uR), _p(dep))
+    return n, uR[:len(kpsL)].copy(), dep[:len(kpsL)].copy()

@@ -1,0 +1,166 @@
+/*
+ * orb_oracle.h -- CPU restatement of the ORB-SLAM2 front-end feature path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped HIP library links, loads or
+ * calls this code; it exists so tests (and the bench's cpu_baseline leg) can
+ * check the GPU path against a scalar statement of the reference algorithm.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
+ * this path and its arithmetic lives in OpenCV (not vendored, pinned only as
+ * ">= 2.4.3", tested 2.4.11 / 3.2), which is absent here.  The OpenCV routines
+ * (resize INTER_LINEAR 8U, copyMakeBorder REFLECT_101, FAST 9_16 + NMS,
+ * fastAtan2, GaussianBlur 7x7 sigma 2 on 8U, cvRound) are restated from their
+ * published generic-C++ algorithms (OpenCV 3.2, no IPP/OpenCL).  Only the
+ * constants the reference itself states (umax table, TH_LOW/TH_HIGH/HISTO_LENGTH,
+ * border example, DescriptorDistance arithmetic) are pinned.
+ *
+ * Every function cites the reference lines it follows, relative to
+ * /root/reference/src/ORB_SLAM2/.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 16
+#define ORC_EDGE 19          /* EDGE_THRESHOLD, src/ORBextractor.cc:74 */
+#define ORC_GRID_COLS 64     /* include/Frame.h:38 */
+#define ORC_GRID_ROWS 48     /* include/Frame.h:37 */
+#define ORC_TH_HIGH 100      /* src/ORBmatcher.cc:37 */
+#define ORC_TH_LOW 50        /* src/ORBmatcher.cc:38 */
+#define ORC_HISTO_LENGTH 30  /* src/ORBmatcher.cc:39 */
+
+/* Binary layout of cv::KeyPoint (28 bytes). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+typedef struct {
+    int nfeatures;
+    float scaleFactor;
+    int nlevels;
+    int iniThFAST;
+    int minThFAST;
+    int gauss_variant; /* 0: kernel 18,34,49,55,... (sum 257); 1: 18,34,48,56,... (sum 256) */
+} orc_params;
+
+/* ---- scalar helpers -------------------------------------------------- */
+int orc_cvround_f(float v);
+float orc_fast_atan2(float y, float x);
+int orc_hamming256(const uint8_t *a, const uint8_t *b);
+
+/* ---- per-extractor tables (ORBextractor ctor, src/ORBextractor.cc:456-577) */
+int orc_tables(const orc_params *p, float *scale, float *inv_scale, float *sigma2,
+               float *inv_sigma2, int *quota, int *umax16);
+void orc_level_size(const orc_params *p, int w, int h, int level, int *lw, int *lh);
+
+/* ---- image primitives -------------------------------------------------- */
+int orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride,
+                         uint8_t *dst, int dw, int dh, int dstride);
+void orc_border_reflect101(uint8_t *interior, int w, int h, int stride, int border);
+void orc_gauss7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride,
+                int variant);
+
+/* cv::FAST(TYPE_9_16) on a (sub-)image; returns number of keypoints, writes up
+ * to cap entries in row-major order.  scores = FAST response. */
+int orc_fast9(const uint8_t *img, int w, int h, int stride, int threshold, int nonmax,
+              int *xs, int *ys, int *scores, int cap);
+/* Threshold-free score A-1 (clamped at 0) of one pixel; needs 3 px margin. */
+int orc_fast_score_pixel(const uint8_t *p, int stride);
+
+/* Per-level FAST over 30-px cells with ini/min threshold fallback
+ * (src/ORBextractor.cc:1018-1107).  Coordinates relative to (16,16). */
+int orc_level_candidates(const uint8_t *plane, int w, int h, int stride, int iniTh,
+                         int minTh, float *xs, float *ys, float *resp, int cap);
+
+/* DistributeOctTree (src/ORBextractor.cc:688-1006) with the deterministic
+ * tie-break (count, creation sequence).  Writes indices (into the input arrays)
+ * of the retained points in output order.  Returns count or <0 on error. */
+int orc_distribute_octree(const float *xs, const float *ys, const float *resp, int n,
+                          int minX, int maxX, int minY, int maxY, int N, int *out_idx,
+                          int cap, int *tie_straddle);
+
+float orc_ic_angle(const uint8_t *plane, int stride, int cx, int cy, const int *umax16);
+void orc_brief(const uint8_t *blurred, int stride, int cx, int cy, float angle_deg,
+               uint8_t *desc32);
+
+/* ---- the extractor ------------------------------------------------------ */
+typedef struct orc_extractor orc_extractor;
+orc_extractor *orc_extractor_create(const orc_params *p);
+void orc_extractor_destroy(orc_extractor *e);
+/* ORBextractor::operator() (src/ORBextractor.cc:1455-1521).  Returns the number
+ * of keypoints (<= cap) or <0. */
+int orc_extract(orc_extractor *e, const uint8_t *img, int w, int h, int stride,
+                orc_keypoint *kps, uint8_t *desc, int cap);
+/* Views into the pyramid of the last orc_extract call (interior pointer; the
+ * allocation carries a 19 px reflect-101 halo around it). blurred=1 returns the
+ * Gaussian-blurred plane used for descriptors (no halo). */
+int orc_extractor_level(orc_extractor *e, int level, int blurred, const uint8_t **ptr,
+                        int *w, int *h, int *stride);
+int orc_extractor_level_count(orc_extractor *e, int level);
+int orc_extractor_tie_straddles(orc_extractor *e);
+
+/* ---- matching ----------------------------------------------------------- */
+void orc_bruteforce(const uint8_t *Q, int nq, const uint8_t *T, int nt, int32_t *best_idx,
+                    int32_t *best_d, int32_t *second_d);
+
+/* Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:270-293,485-500).
+ * cell_start has 64*48+1 entries, cells indexed ix*48+iy; cell_items has n. */
+void orc_grid_build(const orc_keypoint *kps, int n, const float *bounds4,
+                    int32_t *cell_start, int32_t *cell_items);
+/* Frame::GetFeaturesInArea (src/Frame.cc:397-474). Returns count. */
+int orc_features_in_area(const orc_keypoint *kps, const float *bounds4,
+                         const int32_t *cell_start, const int32_t *cell_items, float x,
+                         float y, float r, int minLevel, int maxLevel, int32_t *out, int cap);
+
+/* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1661-1704) on bin sizes. */
+void orc_three_maxima(const int *sizes, int L, int *ind1, int *ind2, int *ind3);
+
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:422-571). */
+int orc_search_for_initialization(const orc_keypoint *kps1, const uint8_t *desc1, int n1,
+                                  const orc_keypoint *kps2, const uint8_t *desc2, int n2,
+                                  const float *bounds4, float *prev_matched_xy,
+                                  int32_t *matches12, int windowSize, float nnratio,
+                                  int checkOri);
+
+/* One windowed query: projection (u,v), radius, octave window, descriptor index
+ * is the query's own index; angle for the rotation histogram; ur = predicted
+ * right coordinate (used only when the train keypoint has uRight > 0). */
+typedef struct {
+    float u, v, r;
+    int32_t minLevel, maxLevel;
+    float angle;
+    float ur;
+    int32_t flags; /* bit0: valid; bit1: a match by this query marks the train keypoint occupied */
+} orc_wquery;
+
+/* mode 0: SearchByProjection(Frame&, vector<MapPoint*>, th)  (src/ORBmatcher.cc:45-129)
+ * mode 1: SearchByProjection(Cur, Last, th, mono)            (src/ORBmatcher.cc:1379-1521)
+ * mode 2: SearchByProjection(Cur, KF, found, th, ORBdist)    (src/ORBmatcher.cc:1523-1650)
+ * occupied[n2]: in = train keypoints already holding a map point; assign[n2]:
+ * out = query index assigned to each train keypoint or -1. Returns nmatches. */
+int orc_search_by_projection(int mode, const orc_wquery *q, const uint8_t *qdesc, int nq,
+                             const orc_keypoint *kps2, const uint8_t *desc2,
+                             const float *uright2, int n2, const float *bounds4,
+                             const uint8_t *occupied, int32_t *assign, int th_dist,
+                             float nnratio, int checkOri);
+
+/* Frame::ComputeStereoMatches (src/Frame.cc:600-774). pyrL/pyrR: arrays of
+ * nlevels interior pointers with strides. */
+int orc_stereo_matches(const orc_keypoint *kpsL, const uint8_t *descL, int nL,
+                       const orc_keypoint *kpsR, const uint8_t *descR, int nR,
+                       const uint8_t *const *pyrL, const uint8_t *const *pyrR,
+                       const int *pyr_w, const int *pyr_h, const int *pyr_strideL,
+                       const int *pyr_strideR, int nlevels, const float *scale,
+                       const float *inv_scale, float bf, float b, float *uRight,
+                       float *depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,83 @@
+"""Seeded synthetic imagery for tests and benchmarks (no datasets are available).
+
+A "scene" is a canvas of overlapping grey rectangles and discs (plenty of FAST
+corners at several scales); frames are crops of the canvas that translate by a
+fixed step per frame, plus per-frame sensor noise, so consecutive frames can be
+matched with a known ground-truth shift.
+"""
+import numpy as np
+
+
+def _canvas(w, h, seed, n_shapes):
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 128, np.float32)
+    # low-frequency shading so flat regions are not perfectly flat
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img += 20.0 * np.sin(xx / 97.0) * np.cos(yy / 71.0)
+    for _ in range(n_shapes):
+        g = float(rng.integers(0, 256))
+        cx = int(rng.integers(0, w)); cy = int(rng.integers(0, h))
+        s = int(rng.integers(4, max(8, min(w, h) // 6)))
+        if rng.random() < 0.6:
+            s2 = int(rng.integers(4, max(8, min(w, h) // 6)))
+            img[max(cy - s2, 0):cy + s2, max(cx - s, 0):cx + s] = g
+        else:
+            y0, y1 = max(cy - s, 0), min(cy + s + 1, h)
+            x0, x1 = max(cx - s, 0), min(cx + s + 1, w)
+            sub = img[y0:y1, x0:x1]
+            m = (yy[y0:y1, x0:x1] - cy) ** 2 + (xx[y0:y1, x0:x1] - cx) ** 2 <= s * s
+            sub[m] = g
+    # mild 3x3 box blur: edges span more than one pixel like a real lens
+    p = np.pad(img, 1, mode="edge")
+    img = sum(p[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)) / 9.0
+    return img
+
+
+def sequence(w, h, n_frames, seed=1, n_shapes=None, noise=3.0, step=(2, 1)):
+    """Return uint8 array [n_frames, h, w]; frame k = canvas crop shifted by k*step."""
+    if n_shapes is None:
+        n_shapes = max(60, (w * h) // 768)
+    mx = abs(step[0]) * n_frames + 8
+    my = abs(step[1]) * n_frames + 8
+    can = _canvas(w + mx, h + my, seed, n_shapes)
+    rng = np.random.default_rng(seed + 7919)
+    out = np.empty((n_frames, h, w), np.uint8)
+    for k in range(n_frames):
+        ox = k * step[0] if step[0] >= 0 else mx + k * step[0]
+        oy = k * step[1] if step[1] >= 0 else my + k * step[1]
+        f = can[oy:oy + h, ox:ox + w] + rng.normal(0.0, noise, (h, w)).astype(np.float32)
+        out[k] = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+    return out
+
+
+def stereo_pair(w, h, seed=2, noise=2.0, dmin=4, dmax=60, band=32):
+    """Left/right pair: the right image is the left shifted by a per-row-band disparity."""
+    can = _canvas(w + dmax + 8, h, seed, max(60, (w * h) // 768))
+    rng = np.random.default_rng(seed + 104729)
+    left = can[:, dmax:dmax + w]
+    right = np.empty_like(left)
+    disp = np.empty(h, np.int32)
+    for y0 in range(0, h, band):
+        d = int(rng.integers(dmin, dmax + 1))
+        disp[y0:y0 + band] = d
+        # a point at x in the left image appears at x - d in the right image
+        right[y0:y0 + band] = can[y0:y0 + band, dmax + d:dmax + d + w]
+    nl = rng.normal(0.0, noise, (h, w)).astype(np.float32)
+    nr = rng.normal(0.0, noise, (h, w)).astype(np.float32)
+    L = np.clip(np.rint(left + nl), 0, 255).astype(np.uint8)
+    R = np.clip(np.rint(right + nr), 0, 255).astype(np.uint8)
+    return L, R, disp
+
+
+def descriptors(n, seed):
+    """i.i.d. uniform 256-bit descriptors [n, 32] uint8."""
+    return np.random.default_rng(seed).integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+def planted(Q, seed, flip=0.1):
+    """T = permuted copy of Q with each bit flipped w.p. `flip`; returns (T, perm) with T[i] = noisy Q[perm[i]]."""
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(len(Q))
+    bits = np.unpackbits(Q[perm], axis=1)
+    bits ^= (rng.random(bits.shape) < flip).astype(np.uint8)
+    return np.packbits(bits, axis=1), perm
