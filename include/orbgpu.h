@@ -1,0 +1,234 @@
+/*
+ * orbgpu.h -- C ABI of the MI355X (gfx950) ORB front-end library.
+ *
+ * This is the drop-in boundary for the feature path of ORB-SLAM2: the host C++
+ * classes ORBextractor / ORBmatcher keep their signatures and forward to these
+ * entry points.  Reference citations are relative to
+ * /root/reference/src/ORB_SLAM2/.
+ *
+ * Conventions
+ *  - every function returns 0 (ORBGPU_OK) or a negative ORBGPU_E_* code; nothing
+ *    throws, prints or exits (the reference's operator() is void/no-throw:
+ *    include/ORBextractor.h:59-61);
+ *  - "host" entry points take ordinary host pointers and synchronise before
+ *    returning; "_device" entry points take device pointers, enqueue on the
+ *    handle's stream and return without synchronising;
+ *  - a handle owns its device memory and one HIP stream; different handles may
+ *    be used from different threads concurrently (the reference runs the left
+ *    and right extractor in two threads, src/Frame.cc:78-81); one handle must
+ *    not be used from two threads at once;
+ *  - keypoints use the binary layout of cv::KeyPoint (28 bytes).
+ */
+#ifndef ORBGPU_H
+#define ORBGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBGPU_OK 0
+#define ORBGPU_E_INVALID (-1)     /* bad argument */
+#define ORBGPU_E_NOMEM (-2)       /* host or device allocation failed */
+#define ORBGPU_E_HIP (-3)         /* a HIP runtime call failed (see orbgpu_last_error) */
+#define ORBGPU_E_CAPACITY (-4)    /* an output or internal buffer is too small */
+#define ORBGPU_E_UNSUPPORTED (-5) /* geometry outside the supported range */
+
+#define ORBGPU_MAX_LEVELS 16
+#define ORBGPU_GRID_COLS 64 /* include/Frame.h:38 */
+#define ORBGPU_GRID_ROWS 48 /* include/Frame.h:37 */
+#define ORBGPU_TH_HIGH 100  /* src/ORBmatcher.cc:37 */
+#define ORBGPU_TH_LOW 50    /* src/ORBmatcher.cc:38 */
+#define ORBGPU_HISTO_LENGTH 30 /* src/ORBmatcher.cc:39 */
+
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbgpu_keypoint;
+
+/* Constructor arguments of ORBextractor (include/ORBextractor.h:51-52) plus the
+ * sizing of the device-side working set. */
+typedef struct {
+    int32_t nfeatures;
+    float scaleFactor;
+    int32_t nlevels;
+    int32_t iniThFAST;
+    int32_t minThFAST;
+    int32_t gauss_variant; /* 0: 8-bit Gaussian taps 18,34,49,55,49,34,18; 1: 18,34,48,56,48,34,18 */
+    int32_t device;        /* HIP device ordinal */
+    int32_t max_width;     /* largest image the handle will see */
+    int32_t max_height;
+    int32_t max_batch;     /* frames processed per launch by the batch entry points (>=1) */
+} orbgpu_params;
+
+typedef struct orbgpu_extractor orbgpu_extractor;
+typedef struct orbgpu_matcher orbgpu_matcher;
+
+const char *orbgpu_last_error(void); /* thread-local description of the last failure */
+int orbgpu_device_count(int *count);
+
+/* ---- ORBextractor ------------------------------------------------------- */
+
+/* ORBextractor::ORBextractor (src/ORBextractor.cc:456-577). */
+int orbgpu_extractor_create(const orbgpu_params *p, orbgpu_extractor **out);
+void orbgpu_extractor_destroy(orbgpu_extractor *e);
+/* Use the caller's hipStream_t (as void*) instead of the handle's own stream. */
+int orbgpu_extractor_set_stream(orbgpu_extractor *e, void *hip_stream);
+int orbgpu_extractor_sync(orbgpu_extractor *e);
+
+/* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:63-83) and the per-level
+ * feature quotas mnFeaturesPerLevel.  Any pointer may be NULL. */
+int orbgpu_extractor_tables(const orbgpu_extractor *e, int32_t *nlevels, float *scale,
+                            float *inv_scale, float *sigma2, float *inv_sigma2,
+                            int32_t *features_per_level);
+/* Upper bound of keypoints one frame can yield (sizing of output buffers). */
+int orbgpu_extractor_max_keypoints(const orbgpu_extractor *e, int32_t *max_kp);
+
+/* ORBextractor::operator() (src/ORBextractor.cc:1455-1521) for one host image.
+ * The mask argument of the reference is ignored there too and has no
+ * counterpart.  An empty image (w or h == 0, or img NULL) yields *n_out = 0. */
+int orbgpu_extract(orbgpu_extractor *e, const uint8_t *img, int32_t w, int32_t h,
+                   int32_t stride, orbgpu_keypoint *kps, uint8_t *desc, int32_t capacity,
+                   int32_t *n_out);
+
+/* Batch of host images, all w x h: frame f outputs start at kps + f*capacity,
+ * desc + f*capacity*32; counts[f] keypoints are valid. */
+int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg,
+                         int32_t w, int32_t h, int32_t stride, orbgpu_keypoint *kps,
+                         uint8_t *desc, int32_t capacity, int32_t *counts);
+
+/* Same, device-resident and asynchronous: d_imgs holds nimg images, image f at
+ * d_imgs + f*frame_stride (row pitch `stride`); outputs are device buffers.
+ * nimg <= max_batch. */
+int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int32_t nimg,
+                                int32_t w, int32_t h, int32_t stride, size_t frame_stride,
+                                orbgpu_keypoint *d_kps, uint8_t *d_desc, int32_t capacity,
+                                int32_t *d_counts);
+
+/* mvImagePyramid[level] of frame `frame` of the last extract call
+ * (include/ORBextractor.h:85, read by src/Frame.cc:607,697,709,714).
+ * border = 0..19 extra reflect-101 pixels on each side (the reference keeps a
+ * 19 px halo around every level, src/ORBextractor.cc:1538-1586).  blurred != 0
+ * returns the 7x7 Gaussian-blurred level used for descriptors instead
+ * (border must be 0).  dst may be NULL to query the size only. */
+int orbgpu_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, int32_t blurred,
+                         int32_t border, uint8_t *dst, int32_t dst_stride, int32_t *w,
+                         int32_t *h);
+/* Device view of the same plane (interior pointer + pitch); valid until the
+ * next extract call on the handle. */
+int orbgpu_pyramid_level_device(orbgpu_extractor *e, int32_t frame, int32_t level,
+                                int32_t blurred, const uint8_t **d_ptr, int32_t *pitch,
+                                int32_t *w, int32_t *h);
+
+/* Stage outputs of the last extract call, for parity tests: FAST candidates of
+ * one level in the order ComputeKeyPointsOctTree collects them
+ * (src/ORBextractor.cc:1043-1107; coordinates relative to (16,16)), and the
+ * keypoints DistributeOctTree retained (src/ORBextractor.cc:1116-1117). */
+int orbgpu_debug_level_candidates(orbgpu_extractor *e, int32_t frame, int32_t level,
+                                  int32_t *xs, int32_t *ys, int32_t *resp, int32_t capacity,
+                                  int32_t *n_out);
+int orbgpu_debug_level_selected(orbgpu_extractor *e, int32_t frame, int32_t level,
+                                int32_t *xs, int32_t *ys, int32_t *resp, int32_t capacity,
+                                int32_t *n_out);
+
+/* ---- ORBmatcher ---------------------------------------------------------- */
+
+int orbgpu_matcher_create(int32_t device, orbgpu_matcher **out);
+void orbgpu_matcher_destroy(orbgpu_matcher *m);
+int orbgpu_matcher_set_stream(orbgpu_matcher *m, void *hip_stream);
+int orbgpu_matcher_sync(orbgpu_matcher *m);
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1710-1727) for one pair of
+ * 32-byte descriptors in host memory. */
+int orbgpu_descriptor_distance(const uint8_t *a, const uint8_t *b);
+
+/* Brute-force scan (the inner pattern of src/ORBmatcher.cc:205-226, :621-647,
+ * src/MapPoint.cc:302-313): for every query the train descriptor with the
+ * smallest Hamming distance (lowest index wins ties), that distance and the
+ * second-smallest distance.  nt == 0 gives idx -1 and distances 256. */
+int orbgpu_hamming_bruteforce(orbgpu_matcher *m, const uint8_t *Q, int32_t nq,
+                              const uint8_t *T, int32_t nt, int32_t *best_idx,
+                              int32_t *best_d, int32_t *second_d);
+int orbgpu_hamming_bruteforce_device(orbgpu_matcher *m, const uint8_t *d_Q, int32_t nq,
+                                     const uint8_t *d_T, int32_t nt, int32_t *d_best_idx,
+                                     int32_t *d_best_d, int32_t *d_second_d);
+
+/* One windowed query of the SearchByProjection family: projection (u,v), search
+ * radius r (already multiplied by the level scale), octave window as
+ * Frame::GetFeaturesInArea takes it (src/Frame.cc:397), the query keypoint's
+ * angle for the rotation histogram, and the predicted right-image coordinate
+ * ur (compared only against train keypoints with uRight > 0). */
+typedef struct {
+    float u, v, r;
+    int32_t minLevel, maxLevel;
+    float angle;
+    float ur;
+    int32_t flags; /* bit0: query is valid; bit1: its match marks the train keypoint occupied */
+} orbgpu_wquery;
+
+#define ORBGPU_MODE_LOCAL_MAP 0  /* SearchByProjection(Frame&, vector<MapPoint*>&, th)   src/ORBmatcher.cc:45-129   */
+#define ORBGPU_MODE_LAST_FRAME 1 /* SearchByProjection(Cur, Last, th, bMono)            src/ORBmatcher.cc:1379-1521 */
+#define ORBGPU_MODE_KEYFRAME 2   /* SearchByProjection(Cur, KF, found, th, ORBdist)      src/ORBmatcher.cc:1523-1650 */
+
+/* Windowed Hamming matching with the reference's sequential semantics (queries
+ * are resolved in index order; a train keypoint claimed by an earlier query is
+ * skipped by later ones).  bounds4 = {mnMinX, mnMinY, mnMaxX, mnMaxY} of the
+ * train frame.  uright (nullable) = mvuRight of the train frame; occupied
+ * (nullable) = 1 where the train keypoint already holds a map point.  Output:
+ * assign[n2] = index of the query whose map point ends up on each train
+ * keypoint or -1; *nmatches = the reference's return value. */
+int orbgpu_search_by_projection(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q,
+                                const uint8_t *qdesc, int32_t nq, const orbgpu_keypoint *kps2,
+                                const uint8_t *desc2, const float *uright2, int32_t n2,
+                                const float *bounds4, const uint8_t *occupied,
+                                int32_t *assign, int32_t th_dist, float nnratio,
+                                int32_t check_orientation, int32_t *nmatches);
+
+/* Device-resident batch: pair p matches queries [p] against train frame [p].
+ * Arrays are strided by q_capacity / t_capacity entries per pair; nq[p], n2[p]
+ * are device arrays of valid counts. uright/occupied may be NULL. */
+int orbgpu_search_by_projection_batch_device(
+    orbgpu_matcher *m, int32_t mode, int32_t npairs, const orbgpu_wquery *d_q,
+    const uint8_t *d_qdesc, const int32_t *d_nq, int32_t q_capacity,
+    const orbgpu_keypoint *d_kps2, const uint8_t *d_desc2, const float *d_uright2,
+    const int32_t *d_n2, int32_t t_capacity, const float *bounds4_host,
+    const uint8_t *d_occupied, int32_t *d_assign, int32_t th_dist, float nnratio,
+    int32_t check_orientation, int32_t *d_nmatches);
+
+/* Builds SearchByProjection(Cur, Last) queries on the device from the last
+ * frame's keypoints displaced by a known image-plane motion (du, dv): u = x+du,
+ * v = y+dv, r = th*scale[octave], levels octave-1..octave+1, all valid and
+ * claiming.  This stands in for the pose-based projection of
+ * src/ORBmatcher.cc:1410-1441, which is outside the descriptor path. */
+int orbgpu_make_shift_queries_device(orbgpu_matcher *m, int32_t npairs,
+                                     const orbgpu_keypoint *d_kps_last, const int32_t *d_n_last,
+                                     int32_t capacity, float du, float dv, float th,
+                                     const float *scale_host, int32_t nlevels,
+                                     const float *bounds4_host, orbgpu_wquery *d_q);
+
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:422-571).
+ * prev_matched_xy[2*n1] in/out (vbPrevMatched), matches12[n1] out. */
+int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1,
+                                     const uint8_t *desc1, int32_t n1,
+                                     const orbgpu_keypoint *kps2, const uint8_t *desc2,
+                                     int32_t n2, const float *bounds4, float *prev_matched_xy,
+                                     int32_t *matches12, int32_t window_size, float nnratio,
+                                     int32_t check_orientation, int32_t *nmatches);
+
+/* Frame::ComputeStereoMatches (src/Frame.cc:600-774).  left/right are
+ * extractor handles whose last extract call processed the stereo pair (frame
+ * index `frame` of that call); keypoints/descriptors are the host outputs of
+ * those calls.  Outputs mvuRight / mvDepth (nL floats each). */
+int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extractor *right,
+                        int32_t frame, const orbgpu_keypoint *kpsL, const uint8_t *descL,
+                        int32_t nL, const orbgpu_keypoint *kpsR, const uint8_t *descR,
+                        int32_t nR, float bf, float b, float *uRight, float *depth,
+                        int32_t *nvalid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,375 @@
+"""ctypes binding of liborbgpu.so and host-side mirrors of the reference classes.
+
+`ORBextractor` and `ORBmatcher` keep the names, argument meaning and return
+conventions of the reference's C++ classes (include/ORBextractor.h:44-113,
+include/ORBmatcher.h:41-103 under /root/reference/src/ORB_SLAM2/), so parity
+tests read like calls into the reference.  All compute happens in the HIP
+library; there is no CPU fallback -- constructing either class without the
+built library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbgpu.so")
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")]
+)
+WQUERY_DTYPE = np.dtype(
+    [("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("minLevel", "<i4"), ("maxLevel", "<i4"),
+     ("angle", "<f4"), ("ur", "<f4"), ("flags", "<i4")]
+)
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+MODE_LOCAL_MAP, MODE_LAST_FRAME, MODE_KEYFRAME = 0, 1, 2
+
+# every symbol include/orbgpu.h declares
+EXPORTS = [
+    "orbgpu_last_error", "orbgpu_device_count",
+    "orbgpu_extractor_create", "orbgpu_extractor_destroy", "orbgpu_extractor_set_stream", "orbgpu_extractor_sync",
+    "orbgpu_extractor_tables", "orbgpu_extractor_max_keypoints", "orbgpu_extract", "orbgpu_extract_batch",
+    "orbgpu_extract_batch_device", "orbgpu_pyramid_level", "orbgpu_pyramid_level_device",
+    "orbgpu_debug_level_candidates", "orbgpu_debug_level_selected",
+    "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync",
+    "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
+    "orbgpu_search_by_projection", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
+    "orbgpu_search_for_initialization", "orbgpu_stereo_match",
+]
+
+
+class OrbGpuError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scaleFactor", C.c_float), ("nlevels", C.c_int32),
+                ("iniThFAST", C.c_int32), ("minThFAST", C.c_int32), ("gauss_variant", C.c_int32),
+                ("device", C.c_int32), ("max_width", C.c_int32), ("max_height", C.c_int32),
+                ("max_batch", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load liborbgpu.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OrbGpuError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or make -C orb_slam2_amd/csrc)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.orbgpu_last_error.restype = C.c_char_p
+        vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+        L.orbgpu_extractor_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+        L.orbgpu_extractor_destroy.argtypes = [vp]
+        L.orbgpu_extractor_destroy.restype = None
+        L.orbgpu_extractor_set_stream.argtypes = [vp, vp]
+        L.orbgpu_extractor_sync.argtypes = [vp]
+        L.orbgpu_extractor_tables.argtypes = [vp, C.POINTER(i32), vp, vp, vp, vp, vp]
+        L.orbgpu_extractor_max_keypoints.argtypes = [vp, C.POINTER(i32)]
+        L.orbgpu_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
+        L.orbgpu_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+        L.orbgpu_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, C.c_size_t, vp, vp, i32, vp]
+        L.orbgpu_pyramid_level.argtypes = [vp, i32, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+        L.orbgpu_pyramid_level_device.argtypes = [vp, i32, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32),
+                                                  C.POINTER(i32)]
+        L.orbgpu_debug_level_candidates.argtypes = [vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]
+        L.orbgpu_debug_level_selected.argtypes = [vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]
+        L.orbgpu_matcher_create.argtypes = [i32, C.POINTER(vp)]
+        L.orbgpu_matcher_destroy.argtypes = [vp]
+        L.orbgpu_matcher_destroy.restype = None
+        L.orbgpu_matcher_set_stream.argtypes = [vp, vp]
+        L.orbgpu_matcher_sync.argtypes = [vp]
+        L.orbgpu_descriptor_distance.argtypes = [vp, vp]
+        L.orbgpu_hamming_bruteforce.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+        L.orbgpu_hamming_bruteforce_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+        L.orbgpu_search_by_projection.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32,
+                                                  C.POINTER(i32)]
+        L.orbgpu_search_by_projection_batch_device.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp,
+                                                               vp, vp, i32, f32, i32, vp]
+        L.orbgpu_make_shift_queries_device.argtypes = [vp, i32, vp, vp, i32, f32, f32, f32, vp, i32, vp, vp]
+        L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
+                                                       C.POINTER(i32)]
+        L.orbgpu_stereo_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().orbgpu_last_error().decode("utf-8", "replace")
+        raise OrbGpuError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def device_count():
+    n = C.c_int(0)
+    load_library().orbgpu_device_count(C.byref(n))
+    return n.value
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM2::ORBextractor (include/ORBextractor.h:44-113)."""
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0, max_width=640,
+                 max_height=480, max_batch=1, gauss_variant=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.params = Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, gauss_variant, device, max_width,
+                             max_height, max_batch)
+        _check(self._lib.orbgpu_extractor_create(C.byref(self.params), C.byref(self._h)), "orbgpu_extractor_create")
+        L = nlevels
+        self._scale = np.zeros(L, np.float32); self._inv = np.zeros(L, np.float32)
+        self._s2 = np.zeros(L, np.float32); self._is2 = np.zeros(L, np.float32)
+        self._quota = np.zeros(L, np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_extractor_tables(self._h, C.byref(n), _p(self._scale), _p(self._inv), _p(self._s2),
+                                                 _p(self._is2), _p(self._quota)), "orbgpu_extractor_tables")
+        mk = C.c_int32()
+        _check(self._lib.orbgpu_extractor_max_keypoints(self._h, C.byref(mk)), "orbgpu_extractor_max_keypoints")
+        self.max_keypoints = mk.value
+        self.nlevels = L
+        self.mvImagePyramid = _PyramidView(self)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.orbgpu_extractor_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- operator() ------------------------------------------------------
+    def __call__(self, image, mask=None):
+        """(keypoints, descriptors) of one uint8 image; `mask` is ignored like in the reference."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise ValueError("image must be a 2-D uint8 array (CV_8UC1)")
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        cap = self.max_keypoints
+        kps = np.zeros(cap, KEYPOINT_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32(0)
+        _check(self._lib.orbgpu_extract(self._h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap,
+                                        C.byref(n)), "orbgpu_extract")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images):
+        """images: uint8 [B,h,w] (contiguous). Returns list of (keypoints, descriptors)."""
+        images = np.ascontiguousarray(images, np.uint8)
+        B, h, w = images.shape
+        cap = self.max_keypoints
+        kps = np.zeros((B, cap), KEYPOINT_DTYPE); desc = np.zeros((B, cap, 32), np.uint8)
+        counts = np.zeros(B, np.int32)
+        ptrs = (C.c_void_p * B)(*[images[i].ctypes.data for i in range(B)])
+        _check(self._lib.orbgpu_extract_batch(self._h, ptrs, B, w, h, images.strides[1], _p(kps), _p(desc), cap,
+                                              _p(counts)), "orbgpu_extract_batch")
+        return [(kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(B)]
+
+    def extract_batch_device(self, d_imgs_ptr, nimg, w, h, stride, frame_stride, d_kps_ptr, d_desc_ptr, capacity,
+                             d_counts_ptr):
+        _check(self._lib.orbgpu_extract_batch_device(self._h, C.c_void_p(d_imgs_ptr), nimg, w, h, stride,
+                                                     C.c_size_t(frame_stride), C.c_void_p(d_kps_ptr),
+                                                     C.c_void_p(d_desc_ptr), capacity, C.c_void_p(d_counts_ptr)),
+               "orbgpu_extract_batch_device")
+
+    def set_stream(self, hip_stream):
+        _check(self._lib.orbgpu_extractor_set_stream(self._h, C.c_void_p(hip_stream)), "orbgpu_extractor_set_stream")
+
+    def sync(self):
+        _check(self._lib.orbgpu_extractor_sync(self._h), "orbgpu_extractor_sync")
+
+    # ---- getters (include/ORBextractor.h:63-83) -----------------------------
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return float(self.params.scaleFactor)
+
+    def GetScaleFactors(self):
+        return self._scale.copy()
+
+    def GetInverseScaleFactors(self):
+        return self._inv.copy()
+
+    def GetScaleSigmaSquares(self):
+        return self._s2.copy()
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._is2.copy()
+
+    @property
+    def mnFeaturesPerLevel(self):
+        return self._quota.copy()
+
+    # ---- pyramid / stage access -------------------------------------------------
+    def pyramid_level(self, level, frame=0, blurred=False, border=0):
+        w, h = C.c_int32(), C.c_int32()
+        _check(self._lib.orbgpu_pyramid_level(self._h, frame, level, int(blurred), border, None, 0, C.byref(w),
+                                              C.byref(h)), "orbgpu_pyramid_level")
+        out = np.zeros((h.value + 2 * border, w.value + 2 * border), np.uint8)
+        _check(self._lib.orbgpu_pyramid_level(self._h, frame, level, int(blurred), border, _p(out), out.strides[0],
+                                              C.byref(w), C.byref(h)), "orbgpu_pyramid_level")
+        return out
+
+    def _debug(self, fn, level, frame, cap):
+        xs = np.zeros(cap, np.int32); ys = np.zeros(cap, np.int32); rs = np.zeros(cap, np.int32)
+        n = C.c_int32()
+        _check(fn(self._h, frame, level, _p(xs), _p(ys), _p(rs), cap, C.byref(n)), "orbgpu_debug_level")
+        return xs[:n.value].copy(), ys[:n.value].copy(), rs[:n.value].copy()
+
+    def debug_level_candidates(self, level, frame=0, cap=1 << 20):
+        return self._debug(self._lib.orbgpu_debug_level_candidates, level, frame, cap)
+
+    def debug_level_selected(self, level, frame=0):
+        return self._debug(self._lib.orbgpu_debug_level_selected, level, frame, 8192)
+
+
+class _PyramidView:
+    """`extractor.mvImagePyramid[level]` -> host copy of that level of the last frame."""
+
+    def __init__(self, ex):
+        self._ex = ex
+
+    def __len__(self):
+        return self._ex.nlevels
+
+    def __getitem__(self, level):
+        return self._ex.pyramid_level(level)
+
+
+class ORBmatcher:
+    """Mirror of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:41-103): the distance
+    primitive, the brute-force scan and the windowed searches."""
+
+    TH_HIGH, TH_LOW, HISTO_LENGTH = TH_HIGH, TH_LOW, HISTO_LENGTH
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        _check(self._lib.orbgpu_matcher_create(device, C.byref(self._h)), "orbgpu_matcher_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.orbgpu_matcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(self._lib.orbgpu_matcher_set_stream(self._h, C.c_void_p(hip_stream)), "orbgpu_matcher_set_stream")
+
+    def sync(self):
+        _check(self._lib.orbgpu_matcher_sync(self._h), "orbgpu_matcher_sync")
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        assert a.size == 32 and b.size == 32
+        return load_library().orbgpu_descriptor_distance(_p(a), _p(b))
+
+    def BruteForce(self, Q, T):
+        Q = np.ascontiguousarray(Q, np.uint8).reshape(-1, 32); T = np.ascontiguousarray(T, np.uint8).reshape(-1, 32)
+        nq, nt = len(Q), len(T)
+        bi = np.zeros(nq, np.int32); b1 = np.zeros(nq, np.int32); b2 = np.zeros(nq, np.int32)
+        _check(self._lib.orbgpu_hamming_bruteforce(self._h, _p(Q), nq, _p(T) if nt else None, nt, _p(bi), _p(b1),
+                                                   _p(b2)), "orbgpu_hamming_bruteforce")
+        return bi, b1, b2
+
+    def bruteforce_device(self, dQ, nq, dT, nt, d_idx, d_d1, d_d2):
+        _check(self._lib.orbgpu_hamming_bruteforce_device(self._h, C.c_void_p(dQ), nq, C.c_void_p(dT), nt,
+                                                          C.c_void_p(d_idx), C.c_void_p(d_d1), C.c_void_p(d_d2)),
+               "orbgpu_hamming_bruteforce_device")
+
+    def SearchByProjection(self, mode, queries, qdesc, kps2, desc2, bounds, uright2=None, occupied=None,
+                           th_dist=TH_HIGH):
+        """Returns (nmatches, assign[n2]); see orbgpu_search_by_projection in include/orbgpu.h."""
+        q = np.ascontiguousarray(queries); assert q.dtype == WQUERY_DTYPE
+        qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        kps2 = np.ascontiguousarray(kps2); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        ur = None if uright2 is None else np.ascontiguousarray(uright2, np.float32)
+        oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        assign = np.zeros(max(len(kps2), 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_by_projection(self._h, mode, _p(q), _p(qdesc), len(q), _p(kps2), _p(desc2),
+                                                     _p(ur), len(kps2), _p(b), _p(oc), _p(assign), th_dist,
+                                                     self.mfNNratio, int(self.mbCheckOrientation), C.byref(n)),
+               "orbgpu_search_by_projection")
+        return n.value, assign[:len(kps2)].copy()
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds, vbPrevMatched, windowSize=10):
+        """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
+        m12 = np.zeros(max(len(kps1), 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_for_initialization(self._h, _p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2),
+                                                          len(kps2), _p(b), _p(prev), _p(m12), windowSize,
+                                                          self.mfNNratio, int(self.mbCheckOrientation), C.byref(n)),
+               "orbgpu_search_for_initialization")
+        return n.value, m12[:len(kps1)].copy(), prev
+
+    def ComputeStereoMatches(self, left, right, kpsL, descL, kpsR, descR, bf, b, frame=0):
+        """Frame::ComputeStereoMatches on the pyramids held by two extractors. Returns (nvalid, mvuRight, mvDepth)."""
+        kpsL = np.ascontiguousarray(kpsL); kpsR = np.ascontiguousarray(kpsR)
+        descL = np.ascontiguousarray(descL, np.uint8); descR = np.ascontiguousarray(descR, np.uint8)
+        uR = np.zeros(max(len(kpsL), 1), np.float32); dep = np.zeros(max(len(kpsL), 1), np.float32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_stereo_match(self._h, left._h, right._h, frame, _p(kpsL), _p(descL), len(kpsL),
+                                             _p(kpsR), _p(descR), len(kpsR), bf, b, _p(uR), _p(dep), C.byref(n)),
+               "orbgpu_stereo_match")
+        return n.value, uR[:len(kpsL)].copy(), dep[:len(kpsL)].copy()
+
+    def search_by_projection_batch_device(self, mode, npairs, d_q, d_qdesc, d_nq, q_cap, d_kps2, d_desc2, d_n2, t_cap,
+                                          bounds, d_assign, d_nmatches, th_dist=TH_HIGH, d_uright2=0, d_occupied=0):
+        b = np.asarray(bounds, np.float32)
+        _check(self._lib.orbgpu_search_by_projection_batch_device(
+            self._h, mode, npairs, C.c_void_p(d_q), C.c_void_p(d_qdesc), C.c_void_p(d_nq), q_cap, C.c_void_p(d_kps2),
+            C.c_void_p(d_desc2), C.c_void_p(d_uright2) if d_uright2 else None, C.c_void_p(d_n2), t_cap, _p(b),
+            C.c_void_p(d_occupied) if d_occupied else None, C.c_void_p(d_assign), th_dist, self.mfNNratio,
+            int(self.mbCheckOrientation), C.c_void_p(d_nmatches)), "orbgpu_search_by_projection_batch_device")
+
+    def make_shift_queries_device(self, npairs, d_kps_last, d_n_last, capacity, du, dv, th, scale, bounds, d_q):
+        sc = np.ascontiguousarray(scale, np.float32); b = np.asarray(bounds, np.float32)
+        _check(self._lib.orbgpu_make_shift_queries_device(self._h, npairs, C.c_void_p(d_kps_last), C.c_void_p(d_n_last),
+                                                          capacity, du, dv, th, _p(sc), len(sc), _p(b), C.c_void_p(d_q)),
+               "orbgpu_make_shift_queries_device")
+
+
+def shift_queries(kps_last, du, dv, th, scale, bounds):
+    """Host twin of orbgpu_make_shift_queries_device (same float arithmetic)."""
+    k = np.ascontiguousarray(kps_last)
+    q = np.zeros(len(k), WQUERY_DTYPE)
+    sc = np.asarray(scale, np.float32)
+    q["u"] = k["x"] + np.float32(du)
+    q["v"] = k["y"] + np.float32(dv)
+    q["r"] = np.float32(th) * sc[k["octave"]]
+    q["minLevel"] = k["octave"] - 1
+    q["maxLevel"] = k["octave"] + 1
+    q["angle"] = k["angle"]
+    q["ur"] = -1.0
+    inside = ~((q["u"] < bounds[0]) | (q["u"] > bounds[2]) | (q["v"] < bounds[1]) | (q["v"] > bounds[3]))
+    q["flags"] = np.where(inside, 3, 0)
+    return q

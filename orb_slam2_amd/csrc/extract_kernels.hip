@@ -1,0 +1,768 @@
+// HIP kernels of the ORB extractor for gfx950 (wave64).
+//
+// Stage order for a batch of frames (one launch per stage covers every frame;
+// the frame index is a grid dimension):
+//   pyr_copy0 -> pyr_resize (levels 1..L-1, dependent chain) -> fast_cells ->
+//   octree -> blur -> describe
+// Reference lines are relative to /root/reference/src/ORB_SLAM2/.
+#include "orbgpu_internal.h"
+
+namespace orbgpu {
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+
+// Store a pixel of a level and the reflect-101 images of it that fall into the
+// 19 px halo (src/ORBextractor.cc:1567-1586).  Needs w,h >= 2*kEdge+2.
+__device__ __forceinline__ void store_with_halo(uint8_t *in, int pitch, int w, int h, int x, int y, uint8_t v)
+{
+    const int xm = (x >= 1 && x <= kEdge) ? -x : ((x >= w - 1 - kEdge && x <= w - 2) ? 2 * (w - 1) - x : x);
+    const int ym = (y >= 1 && y <= kEdge) ? -y : ((y >= h - 1 - kEdge && y <= h - 2) ? 2 * (h - 1) - y : y);
+    in[(int64_t)y * pitch + x] = v;
+    if (xm != x) in[(int64_t)y * pitch + xm] = v;
+    if (ym != y) {
+        in[(int64_t)ym * pitch + x] = v;
+        if (xm != x) in[(int64_t)ym * pitch + xm] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pyramid (ORBextractor::ComputePyramid, src/ORBextractor.cc:1528-1592)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ img, int stride, size_t frame_stride,
+                                                   uint8_t *__restrict__ pyr, Geom G)
+{
+    const LevelGeom &g = G.lv[0];
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= g.w) return;
+    const uint8_t v = img[(size_t)f * frame_stride + (size_t)y * stride + x];
+    uint8_t *in = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
+    store_with_halo(in, g.pitch, g.w, g.h, x, y, v);
+}
+
+// cv::resize INTER_LINEAR 8UC1 fixed-point arithmetic (called at :1550) from
+// level l-1 into level l, plus the halo of level l.
+__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, Geom G, int level,
+                                                    const XTab *__restrict__ xtab, const YTab *__restrict__ ytab)
+{
+    const LevelGeom &gd = G.lv[level];
+    const LevelGeom &gs = G.lv[level - 1];
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
+    if (dx >= gd.w || dy >= gd.h) return;
+    const XTab xt = xtab[gd.xtab_off + dx];
+    const YTab yt = ytab[gd.ytab_off + dy];
+    uint8_t *base = pyr + (int64_t)f * G.pyr_frame_bytes;
+    const uint8_t *S = base + interior_off(gs);
+    const uint8_t *S0 = S + (int64_t)yt.sy0 * gs.pitch, *S1 = S + (int64_t)yt.sy1 * gs.pitch;
+    const int sx = xt.sx, sx1 = min(sx + 1, gs.w - 1);
+    const int r0 = S0[sx] * xt.a0 + S0[sx1] * xt.a1;
+    const int r1 = S1[sx] * xt.a0 + S1[sx1] * xt.a1;
+    const int v = (((yt.b0 * (r0 >> 4)) >> 16) + ((yt.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    store_with_halo(base + interior_off(gd), gd.pitch, gd.w, gd.h, dx, dy, (uint8_t)v);
+}
+
+// ---------------------------------------------------------------------------
+// FAST-9/16 per 30 px cell with ini/min threshold fallback and in-cell
+// non-maximum suppression (src/ORBextractor.cc:1043-1107; cv::FAST semantics).
+// One workgroup per (cell, frame).  Output: per-cell ordered list of packed
+// candidates in a fixed-capacity slot + the count.
+// ---------------------------------------------------------------------------
+constexpr int kTP = 68;  // LDS tile pitch
+
+// Strength A of the best 9-long arc: max over the 16 arcs of the minimum
+// signed contrast, both polarities.  A pixel is a FAST corner at threshold t
+// iff A > t, and cv::FAST's response is then A-1.
+__device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
+{
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * kTP + 0];   d[1] = v - c[3 * kTP + 1];   d[2] = v - c[2 * kTP + 2];   d[3] = v - c[1 * kTP + 3];
+    d[4] = v - c[0 * kTP + 3];   d[5] = v - c[-1 * kTP + 3];  d[6] = v - c[-2 * kTP + 2];  d[7] = v - c[-3 * kTP + 1];
+    d[8] = v - c[-3 * kTP + 0];  d[9] = v - c[-3 * kTP - 1];  d[10] = v - c[-2 * kTP - 2]; d[11] = v - c[-1 * kTP - 3];
+    d[12] = v - c[0 * kTP - 3];  d[13] = v - c[1 * kTP - 3];  d[14] = v - c[2 * kTP - 2];  d[15] = v - c[3 * kTP - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int best = -256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        best = max(best, max(lo9, -hi9));
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G,
+                                                    uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts)
+{
+    __shared__ uint8_t tile[kMaxTile * kTP];
+    __shared__ uint8_t score[(kMaxTile - 4) * kTP];  // interior + 1 px zero border
+    __shared__ uint16_t queue[(kMaxTile - 6) * (kMaxTile - 6)];
+    __shared__ int qn;
+    __shared__ int scan_lds[33];
+
+    const int f = blockIdx.y, cell = blockIdx.x, tid = threadIdx.x;
+    int l = 0;
+    while (l + 1 < G.nlevels && cell >= G.lv[l + 1].cell_off) l++;
+    const LevelGeom &g = G.lv[l];
+    const int ci = cell - g.cell_off, ci_i = ci / g.nCols, ci_j = ci - ci_i * g.nCols;
+    const int maxBX = g.w - kMinBorder, maxBY = g.h - kMinBorder;
+    const int iniY = kMinBorder + ci_i * g.hCell, iniX = kMinBorder + ci_j * g.wCell;
+    int32_t *cnt_out = cell_counts + (int64_t)f * G.total_cells + cell;
+    // skip rules of :1053 and :1068 (the column rule uses 6, the row rule 3)
+    if (iniY >= maxBY - 3 || iniX >= maxBX - 6) {
+        if (tid == 0) *cnt_out = 0;
+        return;
+    }
+    const int cw = min(iniX + g.wCell + 6, maxBX) - iniX, ch = min(iniY + g.hCell + 6, maxBY) - iniY;
+    const int wi = cw - 6, hi = ch - 6;
+    if (wi <= 0 || hi <= 0) {
+        if (tid == 0) *cnt_out = 0;
+        return;
+    }
+    const uint8_t *src = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)iniY * g.pitch + iniX;
+    for (int i = tid; i < cw * ch; i += 256) {
+        const int ty = i / cw, tx = i - ty * cw;
+        tile[ty * kTP + tx] = src[(int64_t)ty * g.pitch + tx];
+    }
+    for (int i = tid; i < (hi + 2) * kTP; i += 256) score[i] = 0;
+    if (tid == 0) qn = 0;
+    __syncthreads();
+
+    // stage 1: cheap rejection at the lower threshold; survivors are compacted
+    // into a queue so the expensive arc evaluation runs on dense waves.
+    const int t = G.minTh;
+    for (int i = tid; i < wi * hi; i += 256) {
+        const int y = i / wi, x = i - y * wi;
+        const uint8_t *c = tile + (y + 3) * kTP + (x + 3);
+        const int v = c[0], lo = v - t, hi_ = v + t;
+        // any 9-long arc contains one pixel of each opposite pair (k, k+8)
+#define ORB_CLS(off) ((int)c[off] < lo ? 1 : ((int)c[off] > hi_ ? 2 : 0))
+        int dcls = ORB_CLS(3 * kTP) | ORB_CLS(-3 * kTP);
+        if (dcls) dcls &= ORB_CLS(3) | ORB_CLS(-3);
+        if (dcls) dcls &= (ORB_CLS(2 * kTP + 2) | ORB_CLS(-2 * kTP - 2));
+        if (dcls) dcls &= (ORB_CLS(-2 * kTP + 2) | ORB_CLS(2 * kTP - 2));
+#undef ORB_CLS
+        if (dcls) {
+            const int pos = atomicAdd(&qn, 1);
+            queue[pos] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const int nq = qn;
+    for (int q = tid; q < nq; q += 256) {
+        const int i = queue[q];
+        const int y = i / wi, x = i - y * wi;
+        const int A = fast_arc_strength(tile + (y + 3) * kTP + (x + 3));
+        if (A > t) score[(y + 1) * kTP + (x + 1)] = (uint8_t)(A - 1);
+    }
+    __syncthreads();
+
+    // stage 2: strict 3x3 maximum inside the cell, threshold choice, ordered
+    // (row-major) emission.  Each thread owns a contiguous run of pixels.
+    const int npix = wi * hi, per = (npix + 255) >> 8;
+    const int p0 = tid * per;
+    uint32_t mmax = 0, mini = 0;
+    for (int k = 0; k < per; k++) {
+        const int i = p0 + k;
+        if (i >= npix) break;
+        const int y = i / wi, x = i - y * wi;
+        const uint8_t *s = score + (y + 1) * kTP + (x + 1);
+        const int sc = s[0];
+        if (sc == 0) continue;
+        const bool ismax = sc > s[-1] && sc > s[1] && sc > s[-kTP - 1] && sc > s[-kTP] && sc > s[-kTP + 1] &&
+                           sc > s[kTP - 1] && sc > s[kTP] && sc > s[kTP + 1];
+        if (ismax) {
+            mmax |= 1u << k;
+            if (sc >= G.iniTh) mini |= 1u << k;
+        }
+    }
+    int total;
+    const int packed = __popc(mini) | (__popc(mmax) << 16);
+    const int excl = block_scan_excl(packed, &total, scan_lds);
+    const bool use_ini = (total & 0xFFFF) > 0;
+    const uint32_t m = use_ini ? mini : mmax;
+    int pos = use_ini ? (excl & 0xFFFF) : (excl >> 16);
+    const int count = use_ini ? (total & 0xFFFF) : (total >> 16);
+    uint32_t *slot = slots + (int64_t)f * G.slot_frame_u32 + g.slot_off + (int64_t)ci * g.cell_cap;
+    for (int k = 0; k < per; k++) {
+        if (!(m >> k & 1u)) continue;
+        const int i = p0 + k;
+        const int y = i / wi, x = i - y * wi;
+        const int sc = score[(y + 1) * kTP + (x + 1)];
+        // keypoint coordinates relative to (16,16): sub-image x (+3 apron) + j*wCell (:1099-1100)
+        if (pos < g.cell_cap) slot[pos] = pack_cand(x + 3 + ci_j * g.wCell, y + 3 + ci_i * g.hCell, sc);
+        pos++;
+    }
+    if (tid == 0) *cnt_out = min(count, g.cell_cap);
+}
+
+// ---------------------------------------------------------------------------
+// DistributeOctTree (src/ORBextractor.cc:606-674, 688-1006), one workgroup of
+// 1024 threads per (level, frame).
+//
+// The reference keeps a std::list of nodes and always inserts at the front, so
+// list order == descending creation order; the node arrays here are kept in
+// list order.  A "split pass" divides a set S of nodes given in processing
+// order: the new list is reverse(children in creation order) ++ (nodes not in
+// S, in their old order).  Points of a node are a contiguous, order-preserving
+// range of packed candidates in one of two candidate buffers; a split is a
+// stable 4-way partition of that range into the other buffer.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int qn_count(const QNode &n) { return n.count & 0x7FFFFFFF; }
+__device__ __forceinline__ int qn_buf(const QNode &n) { return (int)((uint32_t)n.count >> 31); }
+
+struct OctCtx {
+    uint32_t *buf[2];
+    QNode *nl[2];
+    int32_t *S;       // node_cap: positions (in the current list) of the nodes to split
+    int32_t *cnt4;    // 4*node_cap: per-S-entry quadrant populations
+    int32_t *cbase;   // node_cap: exclusive prefix of non-empty children per S entry
+    int32_t *mark;    // node_cap: 1 where the list node is in S, later survivor rank
+    int *scan_lds;
+};
+
+// Count quadrant populations of S[0..nS) (wave per node).
+__device__ void oct_count(const OctCtx &c, int cur, int nS)
+{
+    const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int e = wid; e < nS; e += nw) {
+        const QNode n = c.nl[cur][c.S[e]];
+        const int cnt = qn_count(n);
+        const uint32_t *pts = c.buf[qn_buf(n)] + n.start;
+        const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int b = 0; b < cnt; b += 64) {
+            const int i = b + lane;
+            int q = -1;
+            if (i < cnt) {
+                const uint32_t p = pts[i];
+                q = (cand_x(p) < midx ? 0 : 1) | (cand_y(p) < midy ? 0 : 2);
+            }
+            c0 += __popcll(__ballot(q == 0));
+            c1 += __popcll(__ballot(q == 1));
+            c2 += __popcll(__ballot(q == 2));
+            c3 += __popcll(__ballot(q == 3));
+        }
+        if (lane == 0) {
+            c.cnt4[4 * e + 0] = c0; c.cnt4[4 * e + 1] = c1; c.cnt4[4 * e + 2] = c2; c.cnt4[4 * e + 3] = c3;
+        }
+    }
+}
+
+// Apply the split of S[0..nS) using cnt4.  Returns (through shared scalars
+// written by the caller's conventions) the new list size, the number of
+// children created and the number of children holding more than one point.
+__device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int *out_size, int *out_children, int *out_expand)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = lane_id(), wid = tid >> 6, nw = nt >> 6;
+    // children prefix + expandable count
+    int carry = 0, nexp = 0;
+    for (int b = 0; b < nS; b += nt) {
+        const int e = b + tid;
+        int ne = 0, nx = 0;
+        if (e < nS) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int v = c.cnt4[4 * e + q];
+                ne += v > 0;
+                nx += v > 1;
+            }
+        }
+        int total;
+        const int ex = block_scan_excl(ne | (nx << 16), &total, c.scan_lds);
+        if (e < nS) c.cbase[e] = carry + (ex & 0xFFFF);
+        carry += total & 0xFFFF;
+        nexp += total >> 16;
+    }
+    const int nchild = carry;
+    // survivors: list nodes not in S keep their relative order behind the children
+    for (int i = tid; i < size; i += nt) c.mark[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < nS; e += nt) c.mark[c.S[e]] = 1;
+    __syncthreads();
+    carry = 0;
+    for (int b = 0; b < size; b += nt) {
+        const int i = b + tid;
+        const int keep = (i < size) ? (c.mark[i] == 0) : 0;
+        int total;
+        const int ex = block_scan_excl(keep, &total, c.scan_lds);
+        if (keep) c.nl[cur ^ 1][nchild + carry + ex] = c.nl[cur][i];
+        carry += total;
+    }
+    // scatter the points and emit the child nodes
+    for (int e = wid; e < nS; e += nw) {
+        const QNode n = c.nl[cur][c.S[e]];
+        const int cnt = qn_count(n), sb = qn_buf(n), db = sb ^ 1;
+        const uint32_t *pts = c.buf[sb] + n.start;
+        uint32_t *dst = c.buf[db];
+        const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+        const int k0 = c.cnt4[4 * e + 0], k1 = c.cnt4[4 * e + 1], k2 = c.cnt4[4 * e + 2], k3 = c.cnt4[4 * e + 3];
+        const int s0 = n.start, s1 = s0 + k0, s2 = s1 + k1, s3 = s2 + k2;
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        const uint64_t lt = (1ull << lane) - 1ull;
+        for (int b = 0; b < cnt; b += 64) {
+            const int i = b + lane;
+            int q = -1;
+            uint32_t p = 0;
+            if (i < cnt) {
+                p = pts[i];
+                q = (cand_x(p) < midx ? 0 : 1) | (cand_y(p) < midy ? 0 : 2);
+            }
+            const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+            if (q == 0) dst[s0 + r0 + __popcll(b0 & lt)] = p;
+            else if (q == 1) dst[s1 + r1 + __popcll(b1 & lt)] = p;
+            else if (q == 2) dst[s2 + r2 + __popcll(b2 & lt)] = p;
+            else if (q == 3) dst[s3 + r3 + __popcll(b3 & lt)] = p;
+            r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
+        }
+        if (lane < 4) {
+            const int kq = lane == 0 ? k0 : lane == 1 ? k1 : lane == 2 ? k2 : k3;
+            if (kq > 0) {
+                const int before = (lane > 0 && k0 > 0) + (lane > 1 && k1 > 0) + (lane > 2 && k2 > 0);
+                const int created = c.cbase[e] + before;  // creation index within this pass
+                QNode ch;
+                ch.x0 = (lane & 1) ? (int16_t)midx : n.x0;
+                ch.x1 = (lane & 1) ? n.x1 : (int16_t)midx;
+                ch.y0 = (lane & 2) ? (int16_t)midy : n.y0;
+                ch.y1 = (lane & 2) ? n.y1 : (int16_t)midy;
+                ch.start = lane == 0 ? s0 : lane == 1 ? s1 : lane == 2 ? s2 : s3;
+                ch.count = kq | (db << 31);
+                c.nl[cur ^ 1][nchild - 1 - created] = ch;  // push_front: later creations sit nearer the front
+            }
+        }
+    }
+    __syncthreads();
+    *out_size = nchild + (size - nS);
+    *out_children = nchild;
+    *out_expand = nexp;
+}
+
+__global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restrict__ slots,
+                                                 const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,
+                                                 int32_t *scratch, uint32_t *__restrict__ sel,
+                                                 int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,
+                                                 int32_t *__restrict__ status)
+{
+    __shared__ int scan_lds[33];
+    __shared__ unsigned long long keys[4096];
+    __shared__ int root_cnt[kMaxRoots], root_start[kMaxRoots];
+    __shared__ int sh_a;
+
+    const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int lane = lane_id(), wid = tid >> 6, nw = nt >> 6;
+    const LevelGeom &g = G.lv[level];
+    const int N = g.quota;
+    OctCtx c;
+    c.buf[0] = cand + (int64_t)f * G.cand_frame_u32 + g.cand_off;
+    c.buf[1] = c.buf[0] + g.cand_cap;
+    c.nl[0] = nodes + (int64_t)f * G.node_frame + g.node_off;
+    c.nl[1] = c.nl[0] + g.node_cap;
+    int32_t *scr = scratch + ((int64_t)f * G.node_frame + g.node_off) * 4;
+    c.S = scr;
+    c.cnt4 = scr + g.node_cap;
+    c.cbase = scr + 5 * g.node_cap;
+    c.mark = scr + 6 * g.node_cap;
+    c.scan_lds = scan_lds;
+    int32_t *out_count = sel_count + f * G.nlevels + level;
+    uint32_t *out_sel = sel + (int64_t)f * G.total_kp_cap + g.kp_off;
+
+    // ---- gather the per-cell lists into one ordered candidate array ----------
+    const int nCells = g.nCols * g.nRows;
+    const int32_t *cc = cell_counts + (int64_t)f * G.total_cells + g.cell_off;
+    const uint32_t *sl = slots + (int64_t)f * G.slot_frame_u32 + g.slot_off;
+    int M = 0;
+    for (int b = 0; b < nCells; b += nt) {
+        const int ci = b + tid;
+        const int cnt = ci < nCells ? cc[ci] : 0;
+        int total;
+        const int ex = block_scan_excl(cnt, &total, scan_lds);
+        for (int k = 0; k < cnt; k++) c.buf[0][M + ex + k] = sl[(int64_t)ci * g.cell_cap + k];
+        M += total;
+    }
+    if (tid == 0) cand_count[f * G.nlevels + level] = M;
+    if (M == 0) {
+        if (tid == 0) *out_count = 0;
+        return;
+    }
+    __syncthreads();
+
+    // ---- roots (:696-763) -----------------------------------------------------
+    const int nIni = g.nIni;
+    const float hX = g.hX;
+    int rb = 0;  // buffer holding the root ranges
+    if (nIni > 1) {
+        int outpos = 0;
+        for (int r = 0; r < nIni; r++) {
+            const int start = outpos;
+            for (int b = 0; b < M; b += nt) {
+                const int i = b + tid;
+                uint32_t p = 0;
+                int flag = 0;
+                if (i < M) {
+                    p = c.buf[0][i];
+                    flag = ((int)((float)cand_x(p) / hX) == r);
+                }
+                int total;
+                const int ex = block_scan_excl(flag, &total, scan_lds);
+                if (flag) c.buf[1][outpos + ex] = p;
+                outpos += total;
+            }
+            if (tid == 0) { root_cnt[r] = outpos - start; root_start[r] = start; }
+        }
+        rb = 1;
+    } else if (tid == 0) {
+        root_cnt[0] = M; root_start[0] = 0;
+    }
+    __syncthreads();
+    int size = 0;
+    for (int r = 0; r < nIni; r++) {
+        if (root_cnt[r] > 0) {
+            if (tid == 0) {
+                QNode n;
+                n.x0 = (int16_t)(int)(hX * (float)r);
+                n.x1 = (int16_t)(int)(hX * (float)(r + 1));
+                n.y0 = 0;
+                n.y1 = (int16_t)(g.h - 2 * kMinBorder);
+                n.start = root_start[r];
+                n.count = root_cnt[r] | (rb << 31);
+                c.nl[0][size] = n;
+            }
+            size++;
+        }
+    }
+    __syncthreads();
+
+    // ---- subdivision rounds (:778-970) -----------------------------------------
+    int cur = 0;
+    bool finish = false;
+    while (!finish) {
+        const int prevSize = size;
+        // S = every node with more than one point, in list order
+        int nS = 0;
+        for (int b = 0; b < size; b += nt) {
+            const int i = b + tid;
+            const int flag = (i < size) ? (qn_count(c.nl[cur][i]) > 1) : 0;
+            int total;
+            const int ex = block_scan_excl(flag, &total, scan_lds);
+            if (flag) c.S[nS + ex] = i;
+            nS += total;
+        }
+        __syncthreads();
+        if (nS == 0) break;  // nothing can be divided: size == prevSize
+        oct_count(c, cur, nS);
+        __syncthreads();
+        int nchild, nexp;
+        oct_apply(c, cur, size, nS, &size, &nchild, &nexp);
+        cur ^= 1;
+        if (size >= N || size == prevSize) break;
+        if (size + nexp * 3 > N) {
+            // ---- final partial passes (:893-968): largest nodes first --------
+            int lastChildren = nchild;
+            while (true) {
+                const int prev2 = size;
+                // candidates: children of the previous pass holding > 1 point.
+                // key = (count, creation index); processed in descending order.
+                int nC = 0;
+                for (int b = 0; b < lastChildren; b += nt) {
+                    const int i = b + tid;
+                    int flag = 0, cnt = 0;
+                    if (i < lastChildren) {
+                        cnt = qn_count(c.nl[cur][i]);
+                        flag = cnt > 1;
+                    }
+                    int total;
+                    const int ex = block_scan_excl(flag, &total, scan_lds);
+                    if (flag) keys[nC + ex] = ((unsigned long long)cnt << 32) | (unsigned)(lastChildren - 1 - i);
+                    nC += total;
+                }
+                if (nC == 0) { finish = true; break; }
+                int np2 = 1;
+                while (np2 < nC) np2 <<= 1;
+                for (int i = nC + tid; i < np2; i += nt) keys[i] = 0ull;
+                __syncthreads();
+                for (int k = 2; k <= np2; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = tid; i < np2; i += nt) {
+                            const int ixj = i ^ j;
+                            if (ixj > i) {
+                                const unsigned long long a = keys[i], bb = keys[ixj];
+                                const bool desc = ((i & k) == 0);
+                                if (desc ? (a < bb) : (a > bb)) { keys[i] = bb; keys[ixj] = a; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+                for (int i = tid; i < nC; i += nt) c.S[i] = lastChildren - 1 - (int)(keys[i] & 0xFFFFFFFFull);
+                __syncthreads();
+                oct_count(c, cur, nC);
+                __syncthreads();
+                // first j with size + sum_{i<=j}(children_i - 1) >= N
+                int acc = size, jstar = -1;
+                for (int b = 0; b < nC && jstar < 0; b += nt) {
+                    const int e = b + tid;
+                    int gain = 0;
+                    if (e < nC) {
+                        gain = -1;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) gain += c.cnt4[4 * e + q] > 0;
+                    }
+                    int total;
+                    const int ex = block_scan_excl(gain, &total, scan_lds);
+                    if (tid == 0) sh_a = 0x7FFFFFFF;
+                    __syncthreads();
+                    if (e < nC && acc + ex + gain >= N) atomicMin(&sh_a, e);
+                    __syncthreads();
+                    if (sh_a != 0x7FFFFFFF) jstar = sh_a;
+                    acc += total;
+                    __syncthreads();
+                }
+                const int nS2 = jstar >= 0 ? jstar + 1 : nC;
+                oct_apply(c, cur, size, nS2, &size, &nchild, &nexp);
+                cur ^= 1;
+                if (size >= N || size == prev2) { finish = true; break; }
+                lastChildren = nchild;
+            }
+        }
+    }
+
+    // ---- best response per node, list order (:975-1003) --------------------------
+    if (size > g.kp_cap) {
+        if (tid == 0) atomicOr(status, 1);
+        size = g.kp_cap;
+    }
+    for (int e = wid; e < size; e += nw) {
+        const QNode n = c.nl[cur][e];
+        const int cnt = qn_count(n);
+        const uint32_t *pts = c.buf[qn_buf(n)] + n.start;
+        uint32_t best = 0;
+        for (int b = 0; b < cnt; b += 64) {
+            const int i = b + lane;
+            if (i < cnt) {
+                // highest response, earliest position on ties
+                const uint32_t key = ((uint32_t)cand_s(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i);
+                best = max(best, key);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o));
+        if (lane == 0) out_sel[e] = pts[0xFFFFFFu - (best & 0xFFFFFFu)];
+    }
+    if (tid == 0) *out_count = size;
+}
+
+// ---------------------------------------------------------------------------
+// GaussianBlur 7x7, sigma 2, 8-bit fixed point (called at :1502).  All levels
+// in one launch; the 19 px halo of the source supplies the reflect-101 border.
+// ---------------------------------------------------------------------------
+constexpr int kBW = 64, kBH = 16;
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G)
+{
+    __shared__ uint8_t src[(kBH + 6) * 72];
+    __shared__ uint16_t hrow[(kBH + 6) * kBW];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    int l = 0, t = blockIdx.x;
+    while (true) {
+        const int n = ((G.lv[l].w + kBW - 1) / kBW) * ((G.lv[l].h + kBH - 1) / kBH);
+        if (t < n) break;
+        t -= n;
+        l++;
+        if (l >= G.nlevels) return;
+    }
+    const LevelGeom &g = G.lv[l];
+    const int tilesX = (g.w + kBW - 1) / kBW;
+    const int ty0 = (t / tilesX) * kBH, tx0 = (t % tilesX) * kBW;
+    const int k0 = 18, k1 = 34, k2 = G.gauss_variant ? 48 : 49, k3 = G.gauss_variant ? 56 : 55;
+    const uint8_t *in = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
+    // halo reads stay inside the 19 px border as long as the tile overhang is
+    // clamped to the image (columns/rows beyond w,h are never stored).
+    for (int i = tid; i < (kBH + 6) * (kBW + 6); i += 256) {
+        const int r = i / (kBW + 6), cx = i - r * (kBW + 6);
+        const int y = min(ty0 + r - 3, g.h + 2), x = min(tx0 + cx - 3, g.w + 2);
+        src[r * 72 + cx] = in[(int64_t)y * g.pitch + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < (kBH + 6) * kBW; i += 256) {
+        const int r = i >> 6, cx = i & 63;
+        const uint8_t *s = src + r * 72 + cx;
+        hrow[i] = (uint16_t)(k0 * (s[0] + s[6]) + k1 * (s[1] + s[5]) + k2 * (s[2] + s[4]) + k3 * s[3]);
+    }
+    __syncthreads();
+    const int cx = tid & 63, x = tx0 + cx;
+    uint8_t *out = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int r = (tid >> 6) * 4 + rr, y = ty0 + r;
+        const uint16_t *hp = hrow + r * kBW + cx;
+        const int s = k0 * (hp[0] + hp[6 * kBW]) + k1 * (hp[kBW] + hp[5 * kBW]) + k2 * (hp[2 * kBW] + hp[4 * kBW]) + k3 * hp[3 * kBW];
+        if (x < g.w && y < g.h) out[(int64_t)y * g.pitch + x] = (uint8_t)min((s + 32768) >> 16, 255);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Orientation (IC_Angle, :85-130), steered BRIEF (:142-191) and the final
+// keypoint record (:1120-1135, :1511-1517).  One wave per retained keypoint.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    // cv::fastAtan2: float polynomial without fused multiply-add
+    const float rad2deg = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * rad2deg, p3 = -0.3258083974640975f * rad2deg;
+    const float p5 = 0.1555786518463281f * rad2deg, p7 = -0.04432655554792128f * rad2deg;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, cq, c2;
+    if (ax >= ay) {
+        cq = __fdiv_rn(ay, __fadd_rn(ax, 2.220446049250313e-16f));
+        c2 = __fmul_rn(cq, cq);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), cq);
+    } else {
+        cq = __fdiv_rn(ax, __fadd_rn(ay, 2.220446049250313e-16f));
+        c2 = __fmul_rn(cq, cq);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), cq));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, Geom G,
+                                                  const uint32_t *__restrict__ sel, const int32_t *__restrict__ sel_count,
+                                                  const int8_t *__restrict__ pattern, orbgpu_keypoint *__restrict__ kps,
+                                                  uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int capacity,
+                                                  int32_t *__restrict__ status)
+{
+    const int f = blockIdx.y, lane = lane_id();
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= G.total_kp_cap) return;
+    int l = 0;
+    while (l + 1 < G.nlevels && slot >= G.lv[l + 1].kp_off) l++;
+    const LevelGeom &g = G.lv[l];
+    const int i = slot - g.kp_off;
+    const int32_t *sc = sel_count + f * G.nlevels;
+    int off = 0, total = 0;
+    for (int k = 0; k < G.nlevels; k++) {
+        const int n = sc[k];
+        if (k < l) off += n;
+        total += n;
+    }
+    if (slot == 0 && lane == 0) {
+        counts[f] = min(total, capacity);
+        if (total > capacity) atomicOr(status, 2);
+    }
+    if (i >= sc[l]) return;
+    const int oi = off + i;
+    if (oi >= capacity) return;
+
+    const uint32_t p = sel[(int64_t)f * G.total_kp_cap + slot];
+    const int x = cand_x(p) + kMinBorder, y = cand_y(p) + kMinBorder;  // level coordinates (:1129-1130)
+    const uint8_t *img = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch + x;
+
+    // intensity centroid over the circular patch: two rows per step
+    int m10 = 0, m01 = 0;
+    {
+        const int half = lane >> 5, u = (lane & 31) - 15;
+#pragma unroll 4
+        for (int r = 0; r < 16; r++) {
+            const int v = -15 + 2 * r + half;
+            if (v <= 15 && (lane & 31) < 31) {
+                const int av = v < 0 ? -v : v;
+                if (u >= -c_umax[av] && u <= c_umax[av]) {
+                    const int I = img[(int64_t)v * g.pitch + u];
+                    m10 += u * I;
+                    m01 += v * I;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o);
+            m01 += __shfl_xor(m01, o);
+        }
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // steered BRIEF on the blurred level
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
+    const float ang = __fmul_rn(angle, factorPI);
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    const uint8_t *bl = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch + x;
+    uint64_t bits[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const char4 pt = reinterpret_cast<const char4 *>(pattern)[k * 64 + lane];
+        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = bl[(int64_t)r0 * g.pitch + q0], t1 = bl[(int64_t)r1 * g.pitch + q1];
+        bits[k] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        const uint64_t w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        reinterpret_cast<uint64_t *>(desc + ((int64_t)f * capacity + oi) * 32)[lane] = w;
+    }
+    if (lane == 0) {
+        orbgpu_keypoint k;
+        const float fx = (float)x, fy = (float)y;
+        k.x = l ? __fmul_rn(fx, g.scale) : fx;
+        k.y = l ? __fmul_rn(fy, g.scale) : fy;
+        k.size = (float)g.patch_size;
+        k.angle = angle;
+        k.response = (float)cand_s(p);
+        k.octave = l;
+        k.class_id = -1;
+        kps[(int64_t)f * capacity + oi] = k;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------
+int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
+                   const Geom &G, const XTab *xtab, const YTab *ytab)
+{
+    const LevelGeom &g0 = G.lv[0];
+    hipLaunchKernelGGL(k_pyr_copy0, dim3((g0.w + 255) / 256, g0.h, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G);
+    for (int l = 1; l < G.nlevels; l++) {
+        const LevelGeom &g = G.lv[l];
+        hipLaunchKernelGGL(k_pyr_resize, dim3((g.w + 63) / 64, (g.h + 3) / 4, nimg), dim3(256), 0, st, pyr, G, l, xtab, ytab);
+    }
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+int launch_detect(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, uint32_t *slots, int32_t *cell_counts,
+                  uint32_t *cand, QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count,
+                  int32_t *status)
+{
+    hipLaunchKernelGGL(k_fast_cells, dim3(G.total_cells, nimg), dim3(256), 0, st, pyr, G, slots, cell_counts);
+    hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(1024), 0, st, G, slots, cell_counts, cand, nodes, scratch, sel,
+                       sel_count, cand_count, status);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G, const uint32_t *sel,
+                    const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
+                    int capacity, int32_t *status)
+{
+    int tiles = 0;
+    for (int l = 0; l < G.nlevels; l++) tiles += ((G.lv[l].w + kBW - 1) / kBW) * ((G.lv[l].h + kBH - 1) / kBH);
+    hipLaunchKernelGGL(k_blur, dim3(tiles, nimg), dim3(256), 0, st, pyr, blur, G);
+    hipLaunchKernelGGL(k_describe, dim3((G.total_kp_cap + 3) / 4, nimg), dim3(256), 0, st, pyr, blur, G, sel, sel_count,
+                       pattern, kps, desc, counts, capacity, status);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+}  // namespace orbgpu

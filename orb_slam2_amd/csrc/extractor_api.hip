@@ -1,0 +1,563 @@
+// C-ABI entry points of the extractor half of liborbgpu (see include/orbgpu.h).
+// Reference lines are relative to /root/reference/src/ORB_SLAM2/.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "orbgpu_internal.h"
+
+namespace orbgpu {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
+                   const Geom &G, const XTab *xtab, const YTab *ytab);
+int launch_detect(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, uint32_t *slots, int32_t *cell_counts,
+                  uint32_t *cand, QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count,
+                  int32_t *status);
+int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G, const uint32_t *sel,
+                    const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
+                    int capacity, int32_t *status);
+
+static const int8_t kPattern[1024] = {
+#include "brief_pattern.inc"
+};
+
+static inline int cv_round(float v) { return (int)lrintf(v); }  // round half to even, like cvRound
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return ORBGPU_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        if (hipMalloc(&p, need) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes failed", need);
+            return ORBGPU_E_NOMEM;
+        }
+        bytes = need;
+        return ORBGPU_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace orbgpu
+
+using namespace orbgpu;
+
+struct orbgpu_extractor {
+    orbgpu_params p;
+    float scale[ORBGPU_MAX_LEVELS], inv_scale[ORBGPU_MAX_LEVELS], sigma2[ORBGPU_MAX_LEVELS], inv_sigma2[ORBGPU_MAX_LEVELS];
+    int32_t quota[ORBGPU_MAX_LEVELS];
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    Geom G;
+    int geom_w = 0, geom_h = 0;
+    int last_nimg = 0;
+    DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab;
+    DevBuf st_img, st_kps, st_desc, st_counts;  // staging for the host entry points
+    void *h_pinned = nullptr;
+    size_t h_pinned_bytes = 0;
+};
+
+// ORBextractor::ORBextractor tables (src/ORBextractor.cc:469-512).
+static void compute_tables(orbgpu_extractor *e)
+{
+    const int L = e->p.nlevels;
+    e->scale[0] = 1.0f;
+    e->sigma2[0] = 1.0f;
+    for (int i = 1; i < L; i++) {
+        e->scale[i] = e->scale[i - 1] * e->p.scaleFactor;
+        e->sigma2[i] = e->scale[i] * e->scale[i];
+    }
+    for (int i = 0; i < L; i++) {
+        e->inv_scale[i] = 1.0f / e->scale[i];
+        e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+    }
+    const float factor = 1.0f / e->p.scaleFactor;
+    float nDesired = (float)e->p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; l++) {
+        e->quota[l] = cv_round(nDesired);
+        sum += e->quota[l];
+        nDesired *= factor;
+    }
+    e->quota[L - 1] = e->p.nfeatures - sum > 0 ? e->p.nfeatures - sum : 0;
+}
+
+static short sat_short(float v)
+{
+    const int i = cv_round(v);
+    return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i);
+}
+
+// Level geometry for a w x h input, plus the bilinear coefficient tables
+// (cv::resize INTER_LINEAR, fixed point: 11-bit weights from float fractions).
+static int build_geometry(const orbgpu_extractor *e, int w, int h, Geom *G, std::vector<XTab> *xt, std::vector<YTab> *yt)
+{
+    memset(G, 0, sizeof(*G));
+    const int L = e->p.nlevels;
+    G->nlevels = L;
+    G->iniTh = e->p.iniThFAST < 0 ? 0 : e->p.iniThFAST > 255 ? 255 : e->p.iniThFAST;
+    G->minTh = e->p.minThFAST < 0 ? 0 : e->p.minThFAST > 255 ? 255 : e->p.minThFAST;
+    G->gauss_variant = e->p.gauss_variant;
+    int64_t pyr = 0, slot = 0, cand = 0, node = 0;
+    int cells = 0, kp = 0;
+    if (xt) xt->clear();
+    if (yt) yt->clear();
+    for (int l = 0; l < L; l++) {
+        LevelGeom &g = G->lv[l];
+        g.w = cv_round((float)w * e->inv_scale[l]);  // :1536
+        g.h = cv_round((float)h * e->inv_scale[l]);
+        if (g.w < 62 || g.h < 62 || g.w - 2 * kMinBorder > 4095 || g.h - 2 * kMinBorder > 4095) {
+            set_error("level %d is %dx%d: supported level sizes are 62..4127 pixels per side", l, g.w, g.h);
+            return ORBGPU_E_UNSUPPORTED;
+        }
+        g.pitch = (int32_t)align_up(kLeftMargin + g.w + kEdge, 64);
+        g.plane_off = pyr;
+        pyr = align_up(pyr + (int64_t)g.pitch * (g.h + 2 * kEdge), 256);
+        // cell grid (:1033-1040)
+        const float width = (float)(g.w - 2 * kMinBorder), height = (float)(g.h - 2 * kMinBorder);
+        g.nCols = (int)(width / 30.f);
+        g.nRows = (int)(height / 30.f);
+        g.wCell = (int)ceilf(width / (float)g.nCols);
+        g.hCell = (int)ceilf(height / (float)g.nRows);
+        if (g.wCell + 6 > kMaxTile || g.hCell + 6 > kMaxTile) {
+            set_error("level %d: cell %dx%d too large", l, g.wCell, g.hCell);
+            return ORBGPU_E_UNSUPPORTED;
+        }
+        g.cell_off = cells;
+        cells += g.nCols * g.nRows;
+        g.cell_cap = ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2);
+        g.slot_off = slot;
+        slot += (int64_t)g.nCols * g.nRows * g.cell_cap;
+        g.cand_cap = g.nCols * g.nRows * g.cell_cap;
+        g.cand_off = cand;
+        cand += 2 * (int64_t)g.cand_cap;
+        g.quota = e->quota[l];
+        // quadtree roots (:696-699)
+        g.nIni = (int)roundf(width / height);
+        if (g.nIni < 1 || g.nIni > kMaxRoots) {
+            set_error("level %d: aspect ratio %dx%d gives %d quadtree roots (supported 1..%d)", l, g.w, g.h, g.nIni, kMaxRoots);
+            return ORBGPU_E_UNSUPPORTED;
+        }
+        g.hX = width / (float)g.nIni;
+        int nc = g.quota + 3 > 4 * g.nIni ? g.quota + 3 : 4 * g.nIni;
+        g.node_cap = (int32_t)align_up(nc + 1, 4);
+        if (g.node_cap > 4096) {
+            set_error("level %d: %d features exceed the quadtree capacity of 4092 per level", l, g.quota);
+            return ORBGPU_E_UNSUPPORTED;
+        }
+        g.node_off = node;
+        node += 2 * (int64_t)g.node_cap;
+        g.kp_cap = g.node_cap;
+        g.kp_off = kp;
+        kp += g.kp_cap;
+        g.scale = e->scale[l];
+        g.patch_size = (int)(31 * e->scale[l]);  // :1120
+        if (l > 0 && xt && yt) {
+            const LevelGeom &s = G->lv[l - 1];
+            g.xtab_off = (int32_t)xt->size();
+            g.ytab_off = (int32_t)yt->size();
+            const double scale_x = 1. / ((double)g.w / s.w), scale_y = 1. / ((double)g.h / s.h);
+            for (int dx = 0; dx < g.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = (int)floorf(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= s.w - 1) { fx = 0; sx = s.w - 1; }
+                XTab t;
+                t.sx = sx;
+                t.a0 = sat_short((1.f - fx) * 2048);
+                t.a1 = sat_short(fx * 2048);
+                xt->push_back(t);
+            }
+            for (int dy = 0; dy < g.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = (int)floorf(fy);
+                fy -= sy;
+                YTab t;
+                t.sy0 = sy < 0 ? 0 : (sy >= s.h ? s.h - 1 : sy);
+                t.sy1 = sy + 1 < 0 ? 0 : (sy + 1 >= s.h ? s.h - 1 : sy + 1);
+                t.b0 = sat_short((1.f - fy) * 2048);
+                t.b1 = sat_short(fy * 2048);
+                t.pad = 0;
+                yt->push_back(t);
+            }
+        }
+    }
+    G->total_cells = cells;
+    G->total_kp_cap = kp;
+    G->pyr_frame_bytes = align_up(pyr + 64, 256);
+    G->slot_frame_u32 = slot;
+    G->cand_frame_u32 = cand;
+    G->node_frame = node;
+    return ORBGPU_OK;
+}
+
+static int ensure_buffers(orbgpu_extractor *e, const Geom &G, int batch, int img_w, int img_h)
+{
+    int rc;
+    const size_t B = (size_t)batch;
+#define ENS(buf, bytes) if ((rc = e->buf.ensure(bytes)) != ORBGPU_OK) return rc
+    ENS(pyr, B * (size_t)G.pyr_frame_bytes);
+    ENS(blur, B * (size_t)G.pyr_frame_bytes);
+    ENS(slots, B * (size_t)G.slot_frame_u32 * 4);
+    ENS(cell_counts, B * (size_t)G.total_cells * 4);
+    ENS(cand, B * (size_t)G.cand_frame_u32 * 4);
+    ENS(nodes, B * (size_t)G.node_frame * sizeof(QNode));
+    ENS(scratch, B * (size_t)G.node_frame * 4 * sizeof(int32_t));
+    ENS(sel, B * (size_t)G.total_kp_cap * 4);
+    ENS(sel_count, B * ORBGPU_MAX_LEVELS * 4);
+    ENS(cand_count, B * ORBGPU_MAX_LEVELS * 4);
+    ENS(status, 64);
+    ENS(st_img, B * (size_t)img_w * img_h);
+    ENS(st_kps, B * (size_t)G.total_kp_cap * sizeof(orbgpu_keypoint));
+    ENS(st_desc, B * (size_t)G.total_kp_cap * 32);
+    ENS(st_counts, B * 4);
+#undef ENS
+    const size_t pin = B * (size_t)G.total_kp_cap * (sizeof(orbgpu_keypoint) + 32) + B * 4 + 64;
+    if (pin > e->h_pinned_bytes) {
+        if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+        e->h_pinned = nullptr;
+        e->h_pinned_bytes = 0;
+        if (hipHostMalloc(&e->h_pinned, pin, hipHostMallocDefault) != hipSuccess) {
+            set_error("hipHostMalloc of %zu bytes failed", pin);
+            return ORBGPU_E_NOMEM;
+        }
+        e->h_pinned_bytes = pin;
+    }
+    return ORBGPU_OK;
+}
+
+// Select the geometry for w x h (recomputing tables when the size changes).
+static int set_geometry(orbgpu_extractor *e, int w, int h)
+{
+    if (w == e->geom_w && h == e->geom_h) return ORBGPU_OK;
+    if (w > e->p.max_width || h > e->p.max_height) {
+        set_error("image %dx%d exceeds the handle's max %dx%d", w, h, e->p.max_width, e->p.max_height);
+        return ORBGPU_E_INVALID;
+    }
+    Geom G;
+    std::vector<XTab> xt;
+    std::vector<YTab> yt;
+    int rc = build_geometry(e, w, h, &G, &xt, &yt);
+    if (rc) return rc;
+    if ((rc = ensure_buffers(e, G, e->p.max_batch, w, h))) return rc;
+    if ((rc = e->xtab.ensure(xt.size() * sizeof(XTab) + 16))) return rc;
+    if ((rc = e->ytab.ensure(yt.size() * sizeof(YTab) + 16))) return rc;
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    ORBGPU_HIP_CHECK(hipMemcpy(e->xtab.p, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice));
+    ORBGPU_HIP_CHECK(hipMemcpy(e->ytab.p, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice));
+    e->G = G;
+    e->geom_w = w;
+    e->geom_h = h;
+    return ORBGPU_OK;
+}
+
+extern "C" {
+
+const char *orbgpu_last_error(void) { return g_err; }
+
+int orbgpu_device_count(int *count)
+{
+    if (!count) return ORBGPU_E_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return ORBGPU_OK;
+}
+
+int orbgpu_extractor_create(const orbgpu_params *p, orbgpu_extractor **out)
+{
+    if (!p || !out) return ORBGPU_E_INVALID;
+    *out = nullptr;
+    if (p->nlevels < 1 || p->nlevels > ORBGPU_MAX_LEVELS || p->nfeatures < 0 || !(p->scaleFactor > 1.0f) ||
+        p->max_batch < 1 || p->max_width < 1 || p->max_height < 1) {
+        set_error("invalid extractor parameters");
+        return ORBGPU_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_error("no HIP device available: the ORB extractor needs a GPU");
+        return ORBGPU_E_HIP;
+    }
+    if (p->device < 0 || p->device >= ndev) {
+        set_error("device %d out of range (%d devices)", p->device, ndev);
+        return ORBGPU_E_INVALID;
+    }
+    orbgpu_extractor *e = new (std::nothrow) orbgpu_extractor();
+    if (!e) return ORBGPU_E_NOMEM;
+    e->p = *p;
+    compute_tables(e);
+    int rc = ORBGPU_OK;
+    do {
+        if (hipSetDevice(p->device) != hipSuccess) { set_error("hipSetDevice failed"); rc = ORBGPU_E_HIP; break; }
+        if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = ORBGPU_E_HIP; break; }
+        e->stream = e->own_stream;
+        if ((rc = e->pattern.ensure(1024))) break;
+        if (hipMemcpy(e->pattern.p, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess) { set_error("pattern upload failed"); rc = ORBGPU_E_HIP; break; }
+        // validate and size for the largest image up front
+        if ((rc = set_geometry(e, p->max_width, p->max_height))) break;
+        if (hipMemset(e->status.p, 0, 64) != hipSuccess) { rc = ORBGPU_E_HIP; break; }
+    } while (0);
+    if (rc) {
+        orbgpu_extractor_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return ORBGPU_OK;
+}
+
+void orbgpu_extractor_destroy(orbgpu_extractor *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->p.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    DevBuf *bufs[] = {&e->pyr, &e->blur, &e->slots, &e->cell_counts, &e->cand, &e->nodes, &e->scratch, &e->sel, &e->sel_count,
+                      &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->st_img, &e->st_kps, &e->st_desc, &e->st_counts};
+    for (DevBuf *b : bufs) b->release();
+    if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int orbgpu_extractor_set_stream(orbgpu_extractor *e, void *hip_stream)
+{
+    if (!e) return ORBGPU_E_INVALID;
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return ORBGPU_OK;
+}
+
+int orbgpu_extractor_sync(orbgpu_extractor *e)
+{
+    if (!e) return ORBGPU_E_INVALID;
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return ORBGPU_OK;
+}
+
+int orbgpu_extractor_tables(const orbgpu_extractor *e, int32_t *nlevels, float *scale, float *inv_scale, float *sigma2,
+                            float *inv_sigma2, int32_t *features_per_level)
+{
+    if (!e) return ORBGPU_E_INVALID;
+    const int L = e->p.nlevels;
+    if (nlevels) *nlevels = L;
+    for (int i = 0; i < L; i++) {
+        if (scale) scale[i] = e->scale[i];
+        if (inv_scale) inv_scale[i] = e->inv_scale[i];
+        if (sigma2) sigma2[i] = e->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = e->inv_sigma2[i];
+        if (features_per_level) features_per_level[i] = e->quota[i];
+    }
+    return ORBGPU_OK;
+}
+
+int orbgpu_extractor_max_keypoints(const orbgpu_extractor *e, int32_t *max_kp)
+{
+    if (!e || !max_kp) return ORBGPU_E_INVALID;
+    *max_kp = e->G.total_kp_cap;
+    return ORBGPU_OK;
+}
+
+int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int32_t nimg, int32_t w, int32_t h,
+                                int32_t stride, size_t frame_stride, orbgpu_keypoint *d_kps, uint8_t *d_desc,
+                                int32_t capacity, int32_t *d_counts)
+{
+    if (!e || !d_imgs || !d_kps || !d_desc || !d_counts || nimg < 1 || capacity < 1 || stride < w) {
+        set_error("orbgpu_extract_batch_device: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (nimg > e->p.max_batch) {
+        set_error("batch of %d exceeds max_batch %d", nimg, e->p.max_batch);
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    int rc = set_geometry(e, w, h);
+    if (rc) return rc;
+    const Geom &G = e->G;
+    hipStream_t st = e->stream;
+    if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, (uint8_t *)e->pyr.p, G, (const XTab *)e->xtab.p,
+                             (const YTab *)e->ytab.p)))
+        return rc;
+    if ((rc = launch_detect(st, nimg, (const uint8_t *)e->pyr.p, G, (uint32_t *)e->slots.p, (int32_t *)e->cell_counts.p,
+                            (uint32_t *)e->cand.p, (QNode *)e->nodes.p, (int32_t *)e->scratch.p, (uint32_t *)e->sel.p,
+                            (int32_t *)e->sel_count.p, (int32_t *)e->cand_count.p, (int32_t *)e->status.p)))
+        return rc;
+    if ((rc = launch_describe(st, nimg, (const uint8_t *)e->pyr.p, (uint8_t *)e->blur.p, G, (const uint32_t *)e->sel.p,
+                              (const int32_t *)e->sel_count.p, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts,
+                              capacity, (int32_t *)e->status.p)))
+        return rc;
+    e->last_nimg = nimg;
+    return ORBGPU_OK;
+}
+
+int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h,
+                         int32_t stride, orbgpu_keypoint *kps, uint8_t *desc, int32_t capacity, int32_t *counts)
+{
+    if (!e || !imgs || !kps || !desc || !counts || nimg < 1 || capacity < 0) {
+        set_error("orbgpu_extract_batch: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (nimg > e->p.max_batch) {
+        set_error("batch of %d exceeds max_batch %d", nimg, e->p.max_batch);
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    int rc = set_geometry(e, w, h);
+    if (rc) return rc;
+    hipStream_t st = e->stream;
+    const int cap = e->G.total_kp_cap;
+    for (int f = 0; f < nimg; f++) {
+        if (!imgs[f]) { set_error("image %d is NULL", f); return ORBGPU_E_INVALID; }
+        ORBGPU_HIP_CHECK(hipMemcpy2DAsync((uint8_t *)e->st_img.p + (size_t)f * w * h, w, imgs[f], stride, w, h,
+                                          hipMemcpyHostToDevice, st));
+    }
+    rc = orbgpu_extract_batch_device(e, (const uint8_t *)e->st_img.p, nimg, w, h, w, (size_t)w * h,
+                                     (orbgpu_keypoint *)e->st_kps.p, (uint8_t *)e->st_desc.p, cap, (int32_t *)e->st_counts.p);
+    if (rc) return rc;
+    uint8_t *hp = (uint8_t *)e->h_pinned;
+    orbgpu_keypoint *h_kps = (orbgpu_keypoint *)hp;
+    uint8_t *h_desc = hp + (size_t)nimg * cap * sizeof(orbgpu_keypoint);
+    int32_t *h_counts = (int32_t *)(h_desc + (size_t)nimg * cap * 32);
+    int32_t *h_status = h_counts + nimg;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(h_kps, e->st_kps.p, (size_t)nimg * cap * sizeof(orbgpu_keypoint), hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(h_desc, e->st_desc.p, (size_t)nimg * cap * 32, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(h_counts, e->st_counts.p, (size_t)nimg * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(h_status, e->status.p, 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    if (*h_status) {
+        set_error("internal capacity exceeded (status %d)", *h_status);
+        (void)hipMemsetAsync(e->status.p, 0, 4, st);
+        return ORBGPU_E_CAPACITY;
+    }
+    for (int f = 0; f < nimg; f++) {
+        const int n = h_counts[f];
+        if (n > capacity) {
+            set_error("frame %d has %d keypoints but capacity is %d", f, n, capacity);
+            return ORBGPU_E_CAPACITY;
+        }
+        counts[f] = n;
+        memcpy(kps + (size_t)f * capacity, h_kps + (size_t)f * cap, (size_t)n * sizeof(orbgpu_keypoint));
+        memcpy(desc + (size_t)f * capacity * 32, h_desc + (size_t)f * cap * 32, (size_t)n * 32);
+    }
+    return ORBGPU_OK;
+}
+
+int orbgpu_extract(orbgpu_extractor *e, const uint8_t *img, int32_t w, int32_t h, int32_t stride, orbgpu_keypoint *kps,
+                   uint8_t *desc, int32_t capacity, int32_t *n_out)
+{
+    if (!e || !n_out) return ORBGPU_E_INVALID;
+    *n_out = 0;
+    if (!img || w <= 0 || h <= 0) return ORBGPU_OK;  // empty image: silent return (:1459-1460)
+    const uint8_t *one[1] = {img};
+    int32_t cnt = 0;
+    int rc = orbgpu_extract_batch(e, one, 1, w, h, stride, kps, desc, capacity, &cnt);
+    if (rc) return rc;
+    *n_out = cnt;
+    return ORBGPU_OK;
+}
+
+int orbgpu_pyramid_level_device(orbgpu_extractor *e, int32_t frame, int32_t level, int32_t blurred, const uint8_t **d_ptr,
+                                int32_t *pitch, int32_t *w, int32_t *h)
+{
+    if (!e || level < 0 || level >= e->p.nlevels || frame < 0 || frame >= e->last_nimg) {
+        set_error("orbgpu_pyramid_level: no such frame/level");
+        return ORBGPU_E_INVALID;
+    }
+    const LevelGeom &g = e->G.lv[level];
+    const uint8_t *base = (const uint8_t *)(blurred ? e->blur.p : e->pyr.p);
+    if (d_ptr) *d_ptr = base + (int64_t)frame * e->G.pyr_frame_bytes + interior_off(g);
+    if (pitch) *pitch = g.pitch;
+    if (w) *w = g.w;
+    if (h) *h = g.h;
+    return ORBGPU_OK;
+}
+
+int orbgpu_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, int32_t blurred, int32_t border, uint8_t *dst,
+                         int32_t dst_stride, int32_t *w, int32_t *h)
+{
+    const uint8_t *src;
+    int32_t pitch, lw, lh;
+    int rc = orbgpu_pyramid_level_device(e, frame, level, blurred, &src, &pitch, &lw, &lh);
+    if (rc) return rc;
+    if (border < 0 || border > kEdge || (blurred && border != 0)) {
+        set_error("border must be 0..19 (0 for blurred levels)");
+        return ORBGPU_E_INVALID;
+    }
+    if (w) *w = lw;
+    if (h) *h = lh;
+    if (!dst) return ORBGPU_OK;
+    if (dst_stride < lw + 2 * border) return ORBGPU_E_INVALID;
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    ORBGPU_HIP_CHECK(hipMemcpy2D(dst, dst_stride, src - (int64_t)border * pitch - border, pitch, lw + 2 * border,
+                                 lh + 2 * border, hipMemcpyDeviceToHost));
+    return ORBGPU_OK;
+}
+
+int orbgpu_debug_level_candidates(orbgpu_extractor *e, int32_t frame, int32_t level, int32_t *xs, int32_t *ys,
+                                  int32_t *resp, int32_t capacity, int32_t *n_out)
+{
+    if (!e || !n_out || level < 0 || level >= e->p.nlevels || frame < 0 || frame >= e->last_nimg) return ORBGPU_E_INVALID;
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    const Geom &G = e->G;
+    const LevelGeom &g = G.lv[level];
+    const int nCells = g.nCols * g.nRows;
+    std::vector<int32_t> cc(nCells);
+    std::vector<uint32_t> sl((size_t)nCells * g.cell_cap);
+    ORBGPU_HIP_CHECK(hipMemcpy(cc.data(), (int32_t *)e->cell_counts.p + (int64_t)frame * G.total_cells + g.cell_off,
+                               (size_t)nCells * 4, hipMemcpyDeviceToHost));
+    ORBGPU_HIP_CHECK(hipMemcpy(sl.data(), (uint32_t *)e->slots.p + (int64_t)frame * G.slot_frame_u32 + g.slot_off,
+                               sl.size() * 4, hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int c = 0; c < nCells; c++)
+        for (int k = 0; k < cc[c]; k++) {
+            const uint32_t p = sl[(size_t)c * g.cell_cap + k];
+            if (n < capacity) { xs[n] = cand_x(p); ys[n] = cand_y(p); resp[n] = cand_s(p); }
+            n++;
+        }
+    *n_out = n;
+    return n > capacity ? ORBGPU_E_CAPACITY : ORBGPU_OK;
+}
+
+int orbgpu_debug_level_selected(orbgpu_extractor *e, int32_t frame, int32_t level, int32_t *xs, int32_t *ys, int32_t *resp,
+                                int32_t capacity, int32_t *n_out)
+{
+    if (!e || !n_out || level < 0 || level >= e->p.nlevels || frame < 0 || frame >= e->last_nimg) return ORBGPU_E_INVALID;
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    const Geom &G = e->G;
+    const LevelGeom &g = G.lv[level];
+    int32_t n = 0;
+    ORBGPU_HIP_CHECK(hipMemcpy(&n, (int32_t *)e->sel_count.p + frame * G.nlevels + level, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> s(n > 0 ? n : 1);
+    if (n > 0)
+        ORBGPU_HIP_CHECK(hipMemcpy(s.data(), (uint32_t *)e->sel.p + (int64_t)frame * G.total_kp_cap + g.kp_off, (size_t)n * 4,
+                                   hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < capacity; i++) { xs[i] = cand_x(s[i]); ys[i] = cand_y(s[i]); resp[i] = cand_s(s[i]); }
+    *n_out = n;
+    return n > capacity ? ORBGPU_E_CAPACITY : ORBGPU_OK;
+}
+
+}  // extern "C"

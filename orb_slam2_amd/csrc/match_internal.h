@@ -1,0 +1,45 @@
+// Argument blocks shared by the matcher kernels and their host launchers.
+#pragma once
+#include "orbgpu_internal.h"
+
+namespace orbgpu {
+
+struct ScaleTab { float s[ORBGPU_MAX_LEVELS]; };
+
+// mode 0..2: ORBGPU_MODE_*; mode 3: SearchForInitialization.
+struct MatchArgs {
+    int32_t mode;
+    const orbgpu_wquery *q;
+    const uint8_t *qdesc;
+    const int32_t *nq;
+    int32_t q_cap;
+    const orbgpu_keypoint *kps2;
+    const uint8_t *desc2;
+    const float *uright2;
+    const int32_t *n2;
+    int32_t t_cap;
+    float minX, minY, maxX, maxY;
+    const uint8_t *occupied;
+    int32_t *assign;   // [pair][t_cap]
+    int32_t *qmatch;   // [pair][q_cap] or null
+    int32_t *scratch;  // [pair][5*q_cap + 2*t_cap]
+    int32_t th_dist;
+    float nnratio;
+    int32_t check_orientation;
+    int32_t *nmatches;  // [pair]
+};
+
+// Frame::ComputeStereoMatches inputs (src/Frame.cc:600-774).
+struct StereoArgs {
+    const orbgpu_keypoint *kpsL; const uint8_t *descL; int32_t nL;
+    const orbgpu_keypoint *kpsR; const uint8_t *descR; int32_t nR;
+    const int32_t *row_start; const int32_t *row_items; int32_t nRows;
+    const uint8_t *pyrL[ORBGPU_MAX_LEVELS]; const uint8_t *pyrR[ORBGPU_MAX_LEVELS];
+    int32_t pitchL[ORBGPU_MAX_LEVELS], pitchR[ORBGPU_MAX_LEVELS], w[ORBGPU_MAX_LEVELS], h[ORBGPU_MAX_LEVELS];
+    float scale[ORBGPU_MAX_LEVELS], inv_scale[ORBGPU_MAX_LEVELS];
+    int32_t nlevels;
+    float bf, b;
+    float *uRight; float *depth; int32_t *best_sad;
+};
+
+}  // namespace orbgpu

@@ -1,0 +1,433 @@
+// C-ABI entry points of the matcher half of liborbgpu (see include/orbgpu.h).
+// Reference lines are relative to /root/reference/src/ORB_SLAM2/.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "match_internal.h"
+#include "orbgpu_internal.h"
+
+namespace orbgpu {
+int launch_bruteforce(hipStream_t st, const uint8_t *d_Q, int nq, const uint8_t *d_T, int nt, int nsplit, int tchunk,
+                      uint2 *part, int32_t *bi, int32_t *b1, int32_t *b2);
+int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs);
+int launch_shift_queries(hipStream_t st, int npairs, const orbgpu_keypoint *kps, const int32_t *n, int capacity, float du,
+                         float dv, float th, const ScaleTab &sc, const float *b4, orbgpu_wquery *q);
+int launch_stereo(hipStream_t st, const StereoArgs &A);
+
+struct MBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return ORBGPU_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        // grow geometrically so repeated calls with slowly growing sizes do not reallocate each time
+        size_t want = need + need / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes failed", want);
+            return ORBGPU_E_NOMEM;
+        }
+        bytes = want;
+        return ORBGPU_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+}  // namespace orbgpu
+
+using namespace orbgpu;
+
+struct orbgpu_matcher {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    MBuf part;     // brute-force partial results
+    MBuf scratch;  // window matcher scratch
+    MBuf stage[12];  // staging for the host entry points
+};
+
+static void choose_split(int nq, int nt, int *nsplit, int *tchunk)
+{
+    // Aim at >= ~4096 workgroups so 256 CUs stay balanced; chunks of at most
+    // 2^20 train descriptors (the local index has 20 bits in the packed key).
+    const int qb = (nq + 255) / 256;
+    int ns = (4096 + qb - 1) / qb;
+    if (ns < 1) ns = 1;
+    int maxns = (nt + 255) / 256;  // keep chunks >= 256 descriptors
+    if (maxns < 1) maxns = 1;
+    if (ns > maxns) ns = maxns;
+    int ch = (nt + ns - 1) / ns;
+    if (ch < 1) ch = 1;
+    if (ch > (1 << 20)) ch = 1 << 20;
+    ns = nt > 0 ? (nt + ch - 1) / ch : 1;
+    *nsplit = ns;
+    *tchunk = ch;
+}
+
+extern "C" {
+
+int orbgpu_matcher_create(int32_t device, orbgpu_matcher **out)
+{
+    if (!out) return ORBGPU_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_error("no HIP device available: the ORB matcher needs a GPU");
+        return ORBGPU_E_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("device %d out of range (%d devices)", device, ndev);
+        return ORBGPU_E_INVALID;
+    }
+    orbgpu_matcher *m = new (std::nothrow) orbgpu_matcher();
+    if (!m) return ORBGPU_E_NOMEM;
+    m->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("stream creation failed");
+        delete m;
+        return ORBGPU_E_HIP;
+    }
+    m->stream = m->own_stream;
+    *out = m;
+    return ORBGPU_OK;
+}
+
+void orbgpu_matcher_destroy(orbgpu_matcher *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    m->part.release();
+    m->scratch.release();
+    for (auto &b : m->stage) b.release();
+    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    delete m;
+}
+
+int orbgpu_matcher_set_stream(orbgpu_matcher *m, void *hip_stream)
+{
+    if (!m) return ORBGPU_E_INVALID;
+    m->stream = hip_stream ? (hipStream_t)hip_stream : m->own_stream;
+    return ORBGPU_OK;
+}
+
+int orbgpu_matcher_sync(orbgpu_matcher *m)
+{
+    if (!m) return ORBGPU_E_INVALID;
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBGPU_OK;
+}
+
+// ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1710-1727).
+int orbgpu_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    int d = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t x, y;
+        memcpy(&x, a + 8 * i, 8);
+        memcpy(&y, b + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+int orbgpu_hamming_bruteforce_device(orbgpu_matcher *m, const uint8_t *d_Q, int32_t nq, const uint8_t *d_T, int32_t nt,
+                                     int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d)
+{
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!d_Q || !d_best_idx || !d_best_d || !d_second_d)) || (nt > 0 && !d_T)) {
+        set_error("orbgpu_hamming_bruteforce: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (nq == 0) return ORBGPU_OK;
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    int nsplit, tchunk;
+    choose_split(nq, nt, &nsplit, &tchunk);
+    int rc = m->part.ensure((size_t)nsplit * nq * sizeof(uint2));
+    if (rc) return rc;
+    return launch_bruteforce(m->stream, d_Q, nq, d_T, nt, nsplit, tchunk, (uint2 *)m->part.p, d_best_idx, d_best_d, d_second_d);
+}
+
+int orbgpu_hamming_bruteforce(orbgpu_matcher *m, const uint8_t *Q, int32_t nq, const uint8_t *T, int32_t nt,
+                              int32_t *best_idx, int32_t *best_d, int32_t *second_d)
+{
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!Q || !best_idx || !best_d || !second_d)) || (nt > 0 && !T)) {
+        set_error("orbgpu_hamming_bruteforce: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (nq == 0) return ORBGPU_OK;
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->stage[0].ensure((size_t)nq * 32))) return rc;
+    if ((rc = m->stage[1].ensure((size_t)(nt > 0 ? nt : 1) * 32))) return rc;
+    if ((rc = m->stage[2].ensure((size_t)nq * 12))) return rc;
+    hipStream_t st = m->stream;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, Q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    if (nt > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[1].p, T, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    int32_t *o = (int32_t *)m->stage[2].p;
+    rc = orbgpu_hamming_bruteforce_device(m, (const uint8_t *)m->stage[0].p, nq, (const uint8_t *)m->stage[1].p, nt, o, o + nq,
+                                          o + 2 * (size_t)nq);
+    if (rc) return rc;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(best_idx, o, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(best_d, o + nq, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(second_d, o + 2 * (size_t)nq, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    return ORBGPU_OK;
+}
+
+static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orbgpu_wquery *d_q, const uint8_t *d_qdesc,
+                      const int32_t *d_nq, int32_t q_cap, const orbgpu_keypoint *d_kps2, const uint8_t *d_desc2,
+                      const float *d_uright2, const int32_t *d_n2, int32_t t_cap, const float *b4, const uint8_t *d_occ,
+                      int32_t *d_assign, int32_t *d_qmatch, int32_t th_dist, float nnratio, int32_t ori, int32_t *d_nmatches)
+{
+    if (npairs < 1 || q_cap < 1 || t_cap < 1 || t_cap > (1 << 20) || !(b4[2] > b4[0]) || !(b4[3] > b4[1])) {
+        set_error("window matcher: invalid sizes or bounds");
+        return ORBGPU_E_INVALID;
+    }
+    int rc = m->scratch.ensure((size_t)npairs * (5 * (size_t)q_cap + 2 * (size_t)t_cap) * 4);
+    if (rc) return rc;
+    MatchArgs A;
+    A.mode = mode;
+    A.q = d_q; A.qdesc = d_qdesc; A.nq = d_nq; A.q_cap = q_cap;
+    A.kps2 = d_kps2; A.desc2 = d_desc2; A.uright2 = d_uright2; A.n2 = d_n2; A.t_cap = t_cap;
+    A.minX = b4[0]; A.minY = b4[1]; A.maxX = b4[2]; A.maxY = b4[3];
+    A.occupied = d_occ; A.assign = d_assign; A.qmatch = d_qmatch; A.scratch = (int32_t *)m->scratch.p;
+    A.th_dist = th_dist; A.nnratio = nnratio; A.check_orientation = ori; A.nmatches = d_nmatches;
+    return launch_match_window(m->stream, A, npairs);
+}
+
+int orbgpu_search_by_projection_batch_device(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orbgpu_wquery *d_q,
+                                             const uint8_t *d_qdesc, const int32_t *d_nq, int32_t q_capacity,
+                                             const orbgpu_keypoint *d_kps2, const uint8_t *d_desc2, const float *d_uright2,
+                                             const int32_t *d_n2, int32_t t_capacity, const float *bounds4_host,
+                                             const uint8_t *d_occupied, int32_t *d_assign, int32_t th_dist, float nnratio,
+                                             int32_t check_orientation, int32_t *d_nmatches)
+{
+    if (!m || mode < 0 || mode > 2 || !d_q || !d_qdesc || !d_nq || !d_kps2 || !d_desc2 || !d_n2 || !bounds4_host || !d_assign ||
+        !d_nmatches) {
+        set_error("orbgpu_search_by_projection_batch_device: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    return run_window(m, mode, npairs, d_q, d_qdesc, d_nq, q_capacity, d_kps2, d_desc2, d_uright2, d_n2, t_capacity, bounds4_host,
+                      d_occupied, d_assign, nullptr, th_dist, nnratio, check_orientation, d_nmatches);
+}
+
+// Host-pointer front end shared by SearchByProjection and SearchForInitialization.
+static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq,
+                       const orbgpu_keypoint *kps2, const uint8_t *desc2, const float *uright2, int32_t n2, const float *b4,
+                       const uint8_t *occupied, int32_t *assign, int32_t *qmatch, int32_t th_dist, float nnratio, int32_t ori,
+                       int32_t *nmatches)
+{
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    const int qc = nq > 0 ? nq : 1, tc = n2 > 0 ? n2 : 1;
+    int rc;
+    if ((rc = m->stage[0].ensure((size_t)qc * sizeof(orbgpu_wquery)))) return rc;
+    if ((rc = m->stage[1].ensure((size_t)qc * 32))) return rc;
+    if ((rc = m->stage[2].ensure((size_t)tc * sizeof(orbgpu_keypoint)))) return rc;
+    if ((rc = m->stage[3].ensure((size_t)tc * 32))) return rc;
+    if ((rc = m->stage[4].ensure((size_t)tc * 4))) return rc;
+    if ((rc = m->stage[5].ensure((size_t)tc))) return rc;
+    if ((rc = m->stage[6].ensure((size_t)tc * 4))) return rc;
+    if ((rc = m->stage[7].ensure((size_t)qc * 4))) return rc;
+    if ((rc = m->stage[8].ensure(64))) return rc;
+    if (nq > 0) {
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, q, (size_t)nq * sizeof(orbgpu_wquery), hipMemcpyHostToDevice, st));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[1].p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    }
+    if (n2 > 0) {
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[2].p, kps2, (size_t)n2 * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[3].p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+        if (uright2) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[4].p, uright2, (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+        if (occupied) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[5].p, occupied, (size_t)n2, hipMemcpyHostToDevice, st));
+    }
+    int32_t hc[4] = {nq, n2, 0, 0};
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[8].p, hc, 16, hipMemcpyHostToDevice, st));
+    int32_t *dc = (int32_t *)m->stage[8].p;
+    rc = run_window(m, mode, 1, (const orbgpu_wquery *)m->stage[0].p, (const uint8_t *)m->stage[1].p, dc, qc,
+                    (const orbgpu_keypoint *)m->stage[2].p, (const uint8_t *)m->stage[3].p,
+                    uright2 ? (const float *)m->stage[4].p : nullptr, dc + 1, tc, b4, occupied ? (const uint8_t *)m->stage[5].p : nullptr,
+                    (int32_t *)m->stage[6].p, (int32_t *)m->stage[7].p, th_dist, nnratio, ori, dc + 2);
+    if (rc) return rc;
+    if (assign && n2 > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(assign, m->stage[6].p, (size_t)n2 * 4, hipMemcpyDeviceToHost, st));
+    if (qmatch && nq > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(qmatch, m->stage[7].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(hc, dc, 16, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    *nmatches = hc[2];
+    return ORBGPU_OK;
+}
+
+int orbgpu_search_by_projection(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq,
+                                const orbgpu_keypoint *kps2, const uint8_t *desc2, const float *uright2, int32_t n2,
+                                const float *bounds4, const uint8_t *occupied, int32_t *assign, int32_t th_dist, float nnratio,
+                                int32_t check_orientation, int32_t *nmatches)
+{
+    if (!m || mode < 0 || mode > 2 || nq < 0 || n2 < 0 || (nq > 0 && (!q || !qdesc)) || (n2 > 0 && (!kps2 || !desc2 || !assign)) ||
+        !bounds4 || !nmatches) {
+        set_error("orbgpu_search_by_projection: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    return window_host(m, mode, q, qdesc, nq, kps2, desc2, uright2, n2, bounds4, occupied, assign, nullptr, th_dist, nnratio,
+                       check_orientation, nmatches);
+}
+
+int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1, const uint8_t *desc1, int32_t n1,
+                                     const orbgpu_keypoint *kps2, const uint8_t *desc2, int32_t n2, const float *bounds4,
+                                     float *prev_matched_xy, int32_t *matches12, int32_t window_size, float nnratio,
+                                     int32_t check_orientation, int32_t *nmatches)
+{
+    if (!m || n1 < 0 || n2 < 0 || (n1 > 0 && (!kps1 || !desc1 || !prev_matched_xy || !matches12)) || (n2 > 0 && (!kps2 || !desc2)) ||
+        !bounds4 || !nmatches) {
+        set_error("orbgpu_search_for_initialization: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    // Window queries around vbPrevMatched, level-0 keypoints only (:444-453).
+    std::vector<orbgpu_wquery> q((size_t)(n1 > 0 ? n1 : 1));
+    for (int i = 0; i < n1; i++) {
+        orbgpu_wquery &w = q[i];
+        w.u = prev_matched_xy[2 * i];
+        w.v = prev_matched_xy[2 * i + 1];
+        w.r = (float)window_size;
+        w.minLevel = kps1[i].octave;
+        w.maxLevel = kps1[i].octave;
+        w.angle = kps1[i].angle;
+        w.ur = -1.0f;
+        w.flags = kps1[i].octave > 0 ? 0 : 1;
+    }
+    int rc = window_host(m, 3, q.data(), desc1, n1, kps2, desc2, nullptr, n2, bounds4, nullptr, nullptr, matches12, ORBGPU_TH_LOW,
+                         nnratio, check_orientation, nmatches);
+    if (rc) return rc;
+    for (int i = 0; i < n1; i++)  // :566-568
+        if (matches12[i] >= 0) {
+            prev_matched_xy[2 * i] = kps2[matches12[i]].x;
+            prev_matched_xy[2 * i + 1] = kps2[matches12[i]].y;
+        }
+    return ORBGPU_OK;
+}
+
+int orbgpu_make_shift_queries_device(orbgpu_matcher *m, int32_t npairs, const orbgpu_keypoint *d_kps_last,
+                                     const int32_t *d_n_last, int32_t capacity, float du, float dv, float th,
+                                     const float *scale_host, int32_t nlevels, const float *bounds4_host, orbgpu_wquery *d_q)
+{
+    if (!m || npairs < 1 || !d_kps_last || !d_n_last || capacity < 1 || !scale_host || nlevels < 1 || nlevels > ORBGPU_MAX_LEVELS ||
+        !bounds4_host || !d_q) {
+        set_error("orbgpu_make_shift_queries_device: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    ScaleTab sc;
+    for (int i = 0; i < ORBGPU_MAX_LEVELS; i++) sc.s[i] = i < nlevels ? scale_host[i] : scale_host[nlevels - 1];
+    return launch_shift_queries(m->stream, npairs, d_kps_last, d_n_last, capacity, du, dv, th, sc, bounds4_host, d_q);
+}
+
+int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extractor *right, int32_t frame,
+                        const orbgpu_keypoint *kpsL, const uint8_t *descL, int32_t nL, const orbgpu_keypoint *kpsR,
+                        const uint8_t *descR, int32_t nR, float bf, float b, float *uRight, float *depth, int32_t *nvalid)
+{
+    if (!m || !left || !right || nL < 0 || nR < 0 || (nL > 0 && (!kpsL || !descL || !uRight || !depth)) ||
+        (nR > 0 && (!kpsR || !descR)) || !nvalid || !(b > 0)) {
+        set_error("orbgpu_stereo_match: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    *nvalid = 0;
+    if (nL == 0) return ORBGPU_OK;
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    StereoArgs A;
+    memset(&A, 0, sizeof(A));
+    int32_t nlev = 0;
+    int rc;
+    if ((rc = orbgpu_extractor_tables(left, &nlev, A.scale, A.inv_scale, nullptr, nullptr, nullptr))) return rc;
+    A.nlevels = nlev;
+    for (int l = 0; l < nlev; l++) {
+        int32_t w2, h2, p2;
+        if ((rc = orbgpu_pyramid_level_device(left, frame, l, 0, &A.pyrL[l], &A.pitchL[l], &A.w[l], &A.h[l]))) return rc;
+        if ((rc = orbgpu_pyramid_level_device(right, frame, l, 0, &A.pyrR[l], &p2, &w2, &h2))) return rc;
+        A.pitchR[l] = p2;
+        if (w2 != A.w[l] || h2 != A.h[l]) {
+            set_error("left and right pyramids differ at level %d", l);
+            return ORBGPU_E_INVALID;
+        }
+    }
+    // the extractors may run on other streams: make their work visible first
+    if ((rc = orbgpu_extractor_sync(left))) return rc;
+    if ((rc = orbgpu_extractor_sync(right))) return rc;
+    const int rc_ = nR > 0 ? nR : 1;
+    if ((rc = m->stage[0].ensure((size_t)nL * sizeof(orbgpu_keypoint)))) return rc;
+    if ((rc = m->stage[1].ensure((size_t)nL * 32))) return rc;
+    if ((rc = m->stage[2].ensure((size_t)rc_ * sizeof(orbgpu_keypoint)))) return rc;
+    if ((rc = m->stage[3].ensure((size_t)rc_ * 32))) return rc;
+    if ((rc = m->stage[4].ensure((size_t)nL * 4 * 3))) return rc;  // uRight, depth, best SAD
+    const int nRows = A.h[0];
+    if ((rc = m->stage[5].ensure(((size_t)nRows + 1) * 4 * 2))) return rc;  // row_start, cursor
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, kpsL, (size_t)nL * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[1].p, descL, (size_t)nL * 32, hipMemcpyHostToDevice, st));
+    if (nR > 0) {
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[2].p, kpsR, (size_t)nR * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[3].p, descR, (size_t)nR * 32, hipMemcpyHostToDevice, st));
+    }
+    // Row table (src/Frame.cc:610-627): right keypoint iR is listed in rows
+    // floor(y-r)..ceil(y+r), r = 2*scale[octave]; lists keep ascending iR.
+    std::vector<int32_t> row_start((size_t)nRows + 1, 0);
+    for (int iR = 0; iR < nR; iR++) {
+        const float r = 2.0f * A.scale[kpsR[iR].octave];
+        const int maxr = (int)ceilf(kpsR[iR].y + r), minr = (int)floorf(kpsR[iR].y - r);
+        for (int y = minr; y <= maxr; y++)
+            if (y >= 0 && y < nRows) row_start[(size_t)y + 1]++;
+    }
+    for (int y = 0; y < nRows; y++) row_start[(size_t)y + 1] += row_start[y];
+    std::vector<int32_t> row_items((size_t)(row_start[nRows] > 0 ? row_start[nRows] : 1));
+    {
+        std::vector<int32_t> cur(row_start.begin(), row_start.end() - 1);
+        for (int iR = 0; iR < nR; iR++) {
+            const float r = 2.0f * A.scale[kpsR[iR].octave];
+            const int maxr = (int)ceilf(kpsR[iR].y + r), minr = (int)floorf(kpsR[iR].y - r);
+            for (int y = minr; y <= maxr; y++)
+                if (y >= 0 && y < nRows) row_items[cur[y]++] = iR;
+        }
+    }
+    if ((rc = m->stage[6].ensure(row_items.size() * 4))) return rc;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[5].p, row_start.data(), row_start.size() * 4, hipMemcpyHostToDevice, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[6].p, row_items.data(), row_items.size() * 4, hipMemcpyHostToDevice, st));
+    A.kpsL = (const orbgpu_keypoint *)m->stage[0].p; A.descL = (const uint8_t *)m->stage[1].p; A.nL = nL;
+    A.kpsR = (const orbgpu_keypoint *)m->stage[2].p; A.descR = (const uint8_t *)m->stage[3].p; A.nR = nR;
+    A.row_start = (const int32_t *)m->stage[5].p; A.row_items = (const int32_t *)m->stage[6].p; A.nRows = nRows;
+    A.bf = bf; A.b = b;
+    A.uRight = (float *)m->stage[4].p; A.depth = A.uRight + nL; A.best_sad = (int32_t *)(A.depth + nL);
+    if ((rc = launch_stereo(st, A))) return rc;
+    std::vector<int32_t> sad((size_t)nL);
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(uRight, A.uRight, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(depth, A.depth, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(sad.data(), A.best_sad, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    // Outlier rejection on the SAD distribution (src/Frame.cc:760-773): sort
+    // (SAD, iL), threshold 1.5*1.4*median.  O(N log N) on <= N entries of host
+    // data; not part of the data-parallel work.
+    std::vector<std::pair<int, int>> v;
+    for (int i = 0; i < nL; i++)
+        if (sad[i] >= 0) v.push_back(std::make_pair(sad[i], i));
+    int valid = (int)v.size();
+    if (!v.empty()) {
+        std::sort(v.begin(), v.end());
+        const float median = (float)v[v.size() / 2].first;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = (int)v.size() - 1; i >= 0; i--) {
+            if ((float)v[i].first < thDist) break;
+            uRight[v[i].second] = -1;
+            depth[v[i].second] = -1;
+            valid--;
+        }
+    }
+    *nvalid = valid;
+    return ORBGPU_OK;
+}
+
+}  // extern "C"

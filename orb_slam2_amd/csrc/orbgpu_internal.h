@@ -1,0 +1,119 @@
+// Internal definitions shared by the HIP translation units of liborbgpu.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbgpu.h"
+
+namespace orbgpu {
+
+constexpr int kEdge = 19;        // EDGE_THRESHOLD: halo kept around every pyramid level
+constexpr int kLeftMargin = 32;  // bytes in front of each interior row (>= kEdge, keeps rows 32 B aligned)
+constexpr int kMinBorder = 16;   // EDGE_THRESHOLD - 3: origin of the FAST search area
+constexpr int kMaxRoots = 16;    // initial quadtree nodes (round(width/height))
+constexpr int kMaxTile = 66;     // largest FAST cell incl. 3 px apron (cells are < 60 px)
+
+// Horizontal / vertical coefficient tables of the fixed-point bilinear resize.
+struct XTab { int32_t sx; int16_t a0, a1; };
+struct YTab { int32_t sy0, sy1; int16_t b0, b1; int32_t pad; };
+
+// Packed FAST candidate: x (13 bits) | y (13 bits) << 13 | score (6 low bits spill) ...
+// Coordinates are relative to (16,16) of the level; both fit in 12 bits for
+// levels up to 4111 px, the score in 8 bits.
+__host__ __device__ inline uint32_t pack_cand(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24); }
+__host__ __device__ inline int cand_x(uint32_t c) { return (int)(c & 0xFFFu); }
+__host__ __device__ inline int cand_y(uint32_t c) { return (int)((c >> 12) & 0xFFFu); }
+__host__ __device__ inline int cand_s(uint32_t c) { return (int)(c >> 24); }
+
+struct LevelGeom {
+    int32_t w, h, pitch;     // interior size and row pitch in bytes
+    int32_t nCols, nRows, wCell, hCell;
+    int32_t cell_off;        // index of this level's first cell within a frame
+    int32_t cell_cap;        // slot entries per cell
+    int32_t cand_cap;        // candidate capacity of the level
+    int32_t quota;           // mnFeaturesPerLevel
+    int32_t node_cap;        // quadtree node capacity
+    int32_t kp_cap, kp_off;  // retained-keypoint capacity / offset within a frame
+    int32_t nIni;            // quadtree roots
+    int32_t xtab_off, ytab_off;
+    float hX;                // root width
+    float scale;             // mvScaleFactor[level]
+    int32_t patch_size;      // (int)(31*scale)
+    int64_t plane_off;       // byte offset of the level's allocation within a frame's pyramid
+    int64_t slot_off;        // u32 offset of the level's cell slots within a frame
+    int64_t cand_off;        // u32 offset of the level's candidate arrays within a frame
+    int64_t node_off;        // node offset within a frame
+};
+
+struct Geom {
+    int32_t nlevels;
+    int32_t total_cells;
+    int32_t total_kp_cap;
+    int32_t iniTh, minTh;
+    int32_t gauss_variant;
+    int64_t pyr_frame_bytes;
+    int64_t slot_frame_u32;
+    int64_t cand_frame_u32;
+    int64_t node_frame;
+    LevelGeom lv[ORBGPU_MAX_LEVELS];
+};
+
+// Quadtree node. Points of a node are the packed candidates at
+// buf[start .. start+count) of candidate array `buf` (0 or 1).
+struct QNode {
+    int16_t x0, x1, y0, y1;
+    int32_t start;
+    int32_t count;  // bit 31: buffer select
+};
+
+__host__ __device__ inline int64_t interior_off(const LevelGeom &g) { return g.plane_off + (int64_t)kEdge * g.pitch + kLeftMargin; }
+
+void set_error(const char *fmt, ...);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Exclusive scan over the block (blockDim.x a multiple of 64, <= 1024).
+// lds needs 33 ints.  Every thread must call it.
+__device__ __forceinline__ int block_scan_excl(int v, int *total, int *lds)
+{
+    const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[wid] = inc;
+    __syncthreads();
+    if (wid == 0) {
+        int wv = lane < nw ? lds[lane] : 0;
+        int winc = wv;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            int t = __shfl_up(winc, o);
+            if (lane >= o) winc += t;
+        }
+        if (lane < nw) lds[16 + lane] = winc - wv;
+        if (lane == nw - 1) lds[32] = winc;
+    }
+    __syncthreads();
+    const int res = inc - v + lds[16 + wid];
+    *total = lds[32];
+    __syncthreads();
+    return res;
+}
+
+#endif
+
+}  // namespace orbgpu
+
+#define ORBGPU_HIP_CHECK(expr)                                                             \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            orbgpu::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return ORBGPU_E_HIP;                                                           \
+        }                                                                                  \
+    } while (0)

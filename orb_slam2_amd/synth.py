@@ -54,14 +54,14 @@ def stereo_pair(w, h, seed=2, noise=2.0, dmin=4, dmax=60, band=32):
     """Left/right pair: the right image is the left shifted by a per-row-band disparity."""
     can = _canvas(w + dmax + 8, h, seed, max(60, (w * h) // 768))
     rng = np.random.default_rng(seed + 104729)
-    left = can[:, dmax:dmax + w]
+    left = can[:, :w]
     right = np.empty_like(left)
     disp = np.empty(h, np.int32)
     for y0 in range(0, h, band):
         d = int(rng.integers(dmin, dmax + 1))
         disp[y0:y0 + band] = d
         # a point at x in the left image appears at x - d in the right image
-        right[y0:y0 + band] = can[y0:y0 + band, dmax + d:dmax + d + w]
+        right[y0:y0 + band] = can[y0:y0 + band, d:d + w]
     nl = rng.normal(0.0, noise, (h, w)).astype(np.float32)
     nr = rng.normal(0.0, noise, (h, w)).astype(np.float32)
     L = np.clip(np.rint(left + nl), 0, 255).astype(np.uint8)

@@ -1,0 +1,157 @@
+"""GPU parity of the matcher entry points against the CPU oracle (bit-exact: integer work)."""
+import numpy as np
+import pytest
+
+from orb_slam2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    from orb_slam2_amd.api import ORBmatcher
+    return ORBmatcher(0.9, True)
+
+
+@pytest.fixture(scope="module")
+def frames(oracle):
+    seq = synth.sequence(640, 480, 3, seed=1)
+    oe = oracle.Extractor(1000)
+    return [oe.extract(f) for f in seq]
+
+
+def test_descriptor_distance_kats(oracle):
+    from orb_slam2_amd.api import ORBmatcher
+    z = np.zeros(32, np.uint8); o = np.full(32, 255, np.uint8)
+    assert ORBmatcher.DescriptorDistance(z, o) == 256
+    assert ORBmatcher.DescriptorDistance(z, z) == 0
+    one = z.copy(); one[17] = 0x10
+    assert ORBmatcher.DescriptorDistance(z, one) == 1
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a = rng.integers(0, 256, 32, dtype=np.uint8); b = rng.integers(0, 256, 32, dtype=np.uint8)
+        ref = int(np.unpackbits(a ^ b).sum())
+        assert ORBmatcher.DescriptorDistance(a, b) == ref == oracle.hamming(a, b)
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 300), (257, 1000), (1000, 1003), (3000, 7)])
+def test_bruteforce_small(matcher, oracle, nq, nt):
+    Q = synth.descriptors(nq, 5); T = synth.descriptors(nt, 6)
+    T[nt // 2] = Q[0]  # an exact hit
+    if nt > 3:
+        T[1] = T[3]    # duplicate train rows: lowest index must win
+        Q[nq - 1] = T[3]
+    got = matcher.BruteForce(Q, T)
+    ref = oracle.bruteforce(Q, T)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+
+
+def test_bruteforce_empty_train(matcher):
+    Q = synth.descriptors(10, 1)
+    bi, b1, b2 = matcher.BruteForce(Q, np.zeros((0, 32), np.uint8))
+    assert (bi == -1).all() and (b1 == 256).all() and (b2 == 256).all()
+
+
+def test_bruteforce_planted_20k(matcher, oracle):
+    Q = synth.descriptors(20000, 5)
+    T, perm = synth.planted(Q, 6)
+    bi, b1, b2 = matcher.BruteForce(Q, T)
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    assert (bi == inv).mean() > 0.999          # planted partner found
+    sub = np.arange(0, 20000, 97)
+    rbi, rb1, rb2 = oracle.bruteforce(Q[sub], T)
+    assert np.array_equal(bi[sub], rbi) and np.array_equal(b1[sub], rb1) and np.array_equal(b2[sub], rb2)
+
+
+def _bounds():
+    return np.array([0, 0, 640, 480], np.float32)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("th", [7.0, 15.0, 40.0])
+def test_search_by_projection_modes(matcher, oracle, frames, mode, th):
+    from orb_slam2_amd import api
+    (k1, d1), (k2, d2) = frames[0], frames[1]
+    sc = oracle.tables(oracle.make_params(1000))["scale"]
+    q = api.shift_queries(k1, -2.0, -1.0, th, sc, _bounds())
+    rng = np.random.default_rng(int(th) + mode)
+    # a mix of claiming / non-claiming / invalid queries and pre-occupied train keypoints
+    q["flags"] = np.where(rng.random(len(q)) < 0.1, q["flags"] & 1, q["flags"])
+    q["flags"] = np.where(rng.random(len(q)) < 0.05, 0, q["flags"])
+    if mode == 0:
+        q["minLevel"] = k1["octave"] - 1
+        q["maxLevel"] = k1["octave"]
+    occ = (rng.random(len(k2)) < 0.1).astype(np.uint8)
+    ur = np.where(rng.random(len(k2)) < 0.5, k2["x"] - 5.0, -1.0).astype(np.float32)
+    q["ur"] = q["u"] - 5.0 + rng.normal(0, th / 2, len(q)).astype(np.float32)
+    q = q.astype(api.WQUERY_DTYPE)
+    matcher.mfNNratio = 0.8
+    n, assign = matcher.SearchByProjection(mode, q, d1, k2, d2, _bounds(), uright2=ur, occupied=occ, th_dist=100)
+    rn, rassign = oracle.search_by_projection(mode, q.view(oracle.WQUERY_DTYPE), d1, k2.view(oracle.KEYPOINT_DTYPE), d2,
+                                              _bounds(), uright2=ur, occupied=occ, th_dist=100, nnratio=0.8,
+                                              checkOri=True)
+    assert n == rn
+    assert np.array_equal(assign, rassign)
+    assert (assign >= 0).sum() > 50
+
+
+def test_search_by_projection_heavy_conflicts(matcher, oracle, frames):
+    """Every query looks at the same window, so claims cascade through the whole query list."""
+    from orb_slam2_amd import api
+    (k1, d1), (k2, d2) = frames[0], frames[2]
+    q = np.zeros(300, api.WQUERY_DTYPE)
+    q["u"] = 320; q["v"] = 240; q["r"] = 400; q["minLevel"] = -1; q["maxLevel"] = -1
+    q["angle"] = k1["angle"][:300]; q["ur"] = -1; q["flags"] = 3
+    for mode in (1, 2):
+        n, assign = matcher.SearchByProjection(mode, q, d1[:300], k2, d2, _bounds(), th_dist=256)
+        rn, rassign = oracle.search_by_projection(mode, q.view(oracle.WQUERY_DTYPE), d1[:300],
+                                                  k2.view(oracle.KEYPOINT_DTYPE), d2, _bounds(), th_dist=256,
+                                                  nnratio=matcher.mfNNratio, checkOri=True)
+        assert n == rn and np.array_equal(assign, rassign)
+
+
+@pytest.mark.parametrize("window,ratio,ori", [(100, 0.9, True), (30, 0.7, False), (500, 0.95, True)])
+def test_search_for_initialization(oracle, frames, window, ratio, ori):
+    from orb_slam2_amd.api import ORBmatcher
+    m = ORBmatcher(ratio, ori)
+    (k1, d1), (k2, d2) = frames[0], frames[1]
+    prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+    n, m12, prev_out = m.SearchForInitialization(k1, d1, k2, d2, _bounds(), prev, window)
+    rn, rm12, rprev = oracle.search_for_initialization(k1.view(oracle.KEYPOINT_DTYPE), d1,
+                                                       k2.view(oracle.KEYPOINT_DTYPE), d2, _bounds(), prev, window,
+                                                       ratio, ori)
+    assert n == rn
+    assert np.array_equal(m12, rm12)
+    assert np.array_equal(prev_out, rprev)
+    if window >= 100:
+        assert n > 20
+
+
+def test_window_match_empty_inputs(matcher):
+    from orb_slam2_amd import api
+    q = np.zeros(0, api.WQUERY_DTYPE)
+    k2 = np.zeros(0, api.KEYPOINT_DTYPE)
+    n, assign = matcher.SearchByProjection(1, q, np.zeros((0, 32), np.uint8), k2, np.zeros((0, 32), np.uint8), _bounds())
+    assert n == 0 and len(assign) == 0
+
+
+def test_stereo_matches(oracle):
+    from orb_slam2_amd.api import ORBextractor, ORBmatcher
+    L, R, disp = synth.stereo_pair(752, 480, seed=3)
+    exL = ORBextractor(1200, 1.2, 8, 20, 7, max_width=752, max_height=480)
+    exR = ORBextractor(1200, 1.2, 8, 20, 7, max_width=752, max_height=480)
+    kL, dL = exL(L)
+    kR, dR = exR(R)
+    bf, fx = 47.90639384423901, 435.2046959714599
+    b = bf / fx
+    m = ORBmatcher()
+    n, uR, dep = m.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, bf, b)
+    t = oracle.tables(oracle.make_params(1200))
+    pyrL = [exL.pyramid_level(l) for l in range(8)]
+    pyrR = [exR.pyramid_level(l) for l in range(8)]
+    rn, ruR, rdep = oracle.stereo_matches(kL.view(oracle.KEYPOINT_DTYPE), dL, kR.view(oracle.KEYPOINT_DTYPE), dR, pyrL,
+                                          pyrR, t["scale"], t["inv_scale"], bf, b)
+    assert n == rn
+    assert np.array_equal(uR, ruR) and np.array_equal(dep, rdep)
+    assert n > 100
