@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the ORB front-end path (extract + windowed match) on MI355X.
+
+One "step" = one batch of B synthetic TUM-like frames (640x480, 1000 features,
+8 levels, scale 1.2, FAST 20/7), already resident in HBM: extract all B frames,
+then SearchByProjection(Cur, Last)-style windowed matching of every frame
+against its predecessor (the predecessor of frame 0 is the last frame of the
+previous step).  Metric: frames/s, whole job (all ranks).
+
+Multi-GPU: one process per GPU, every rank runs the same per-GPU workload on its
+own frames (weak scaling); there is no data-path collective, torch.distributed
+is used only for the barrier and the max-over-ranks of the elapsed time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 640, 480, 1000, 8, 1.2, 20, 7
+STEP = (2, 1)   # per-frame image motion of the synthetic sequence
+TH_PROJ = 15.0  # Tracking.cc:1060-1066 (monocular window)
+HBM_PEAK_GBS = 8000.0
+
+
+def level_pixels(w, h):
+    sc, tot, sizes = 1.0, 0, []
+    f = np.float32(1.0)
+    for l in range(NLEVELS):
+        inv = np.float32(1.0) / f
+        lw, lh = int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))
+        sizes.append((lw, lh))
+        tot += lw * lh
+        f = np.float32(f * np.float32(SCALE))
+    return tot, sizes
+
+
+def cpu_baseline(frames, n_frames):
+    """Oracle (scalar CPU port) timed on one host core over a bounded sample."""
+    from oracle import oracle as O
+    O.build()
+    oe = O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
+    sc = O.tables(oe.p)["scale"]
+    from orb_slam2_amd import api
+    bounds = np.array([0, 0, W, H], np.float32)
+    prev = oe.extract(frames[0])
+    t0 = time.perf_counter()
+    for k in range(1, n_frames + 1):
+        f = frames[k % len(frames)]
+        cur = oe.extract(f)
+        q = api.shift_queries(prev[0], -STEP[0], -STEP[1], TH_PROJ, sc, bounds)
+        O.search_by_projection(1, q.view(O.WQUERY_DTYPE), prev[1], cur[0], cur[1], bounds, th_dist=100, nnratio=0.9,
+                               checkOri=True)
+        prev = cur
+    dt = time.perf_counter() - t0
+    return n_frames / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--cpu-frames", type=int, default=150, help="frames of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from orb_slam2_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    B = args.batch
+    frames = synth.sequence(W, H, B, seed=1 + rank, step=STEP)
+    d_imgs = torch.from_numpy(frames).to(dev)
+
+    ex = api.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H, max_batch=B)
+    mt = api.ORBmatcher(0.9, True, device=local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    ex.set_stream(stream.cuda_stream)
+    mt.set_stream(stream.cuda_stream)
+    cap = ex.max_keypoints
+    scale = ex.GetScaleFactors()
+    bounds = np.array([0, 0, W, H], np.float32)
+
+    # slot 0 = last frame of the previous step, slots 1..B = this step's frames
+    d_kps = torch.zeros((B + 1, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_q = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_assign = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def step():
+        with torch.cuda.stream(stream):
+            ex.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, W * H, d_kps[1].data_ptr(), d_desc[1].data_ptr(), cap,
+                                    d_cnt[1:].data_ptr())
+            mt.make_shift_queries_device(B, d_kps.data_ptr(), d_cnt.data_ptr(), cap, -float(STEP[0]), -float(STEP[1]),
+                                         TH_PROJ, scale, bounds, d_q.data_ptr())
+            mt.search_by_projection_batch_device(api.MODE_LAST_FRAME, B, d_q.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(),
+                                                 cap, d_kps[1].data_ptr(), d_desc[1].data_ptr(), d_cnt[1:].data_ptr(), cap,
+                                                 bounds, d_assign.data_ptr(), d_nm.data_ptr(), th_dist=api.TH_HIGH)
+            # carry the last frame into slot 0 for the next step
+            d_kps[0].copy_(d_kps[B], non_blocking=True)
+            d_desc[0].copy_(d_desc[B], non_blocking=True)
+            d_cnt[0:1].copy_(d_cnt[B:B + 1], non_blocking=True)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ex.profile(True)
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    stage_ms, ncalls = ex.stage_times()
+    ex.profile(False)
+
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+
+    kp_mean = float(d_cnt[1:].float().mean().item())
+    nm_mean = float(d_nm.float().mean().item())
+
+    if rank == 0:
+        P, sizes = level_pixels(W, H)
+        # algorithmic HBM bytes per frame of each extractor stage
+        alg = {
+            "pyramid": W * H + P,            # read the input, write every level once
+            "fast_cells": P,                 # read every level once
+            "octree": 0,
+            "blur": 2 * P,                   # read + write every level
+            "describe": int(kp_mean * 60),   # 28 B keypoint + 32 B descriptor per feature
+        }
+        names = ["pyramid", "fast_cells", "octree", "blur", "describe"]
+        match_ms = gpu_ms / args.steps - float(stage_ms.sum())
+        dom = int(np.argmax(stage_ms))
+        dom_name = names[dom]
+        # the quadtree moves O(N) bytes; price it (if dominant) by the candidate bytes it gathers
+        dom_bytes = alg[dom_name] * B if alg[dom_name] else 4 * 4000 * B
+        achieved = dom_bytes / (float(stage_ms[dom]) * 1e-3) / 1e9
+        frame_alg = W * H + (P - W * H) + P + 2 * P + int(kp_mean * 60)
+        out = {
+            "metric": "frames/sec ORB extract+match at 640x480/1000 kp",
+            "value": world * B * args.steps / wall_max,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "TUM mono 640x480, 1000 features, 8 levels, scale 1.2, FAST 20/7: extract + "
+                                   "SearchByProjection(Cur,Last) th=15 against the previous frame",
+                       "batch_per_gpu": B, "keypoints_per_frame": kp_mean, "matches_per_frame": nm_mean,
+                       "parallelism": "frames sharded across %d GPU(s), no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": float(stage_ms[dom])},
+            "stages_ms_per_step": dict({n: float(v) for n, v in zip(names, stage_ms)}, match=match_ms),
+            "extract_algorithmic_GBps": frame_alg * B / (float(stage_ms.sum()) * 1e-3) / 1e9,
+            "gpu_ms_per_step": gpu_ms / args.steps,
+        }
+        if args.cpu_frames > 0 and world == 1:
+            fps, dt = cpu_baseline(frames, args.cpu_frames)
+            out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "%d frames of the same sequence, extract + windowed match, %.1f s" % (args.cpu_frames, dt)}
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,15 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e);
 int orbgpu_extractor_set_stream(orbgpu_extractor *e, void *hip_stream);
 int orbgpu_extractor_sync(orbgpu_extractor *e);
 
+/* Stage timing (the reference has only wall-clock timing in its example
+ * drivers, Examples/Monocular/mono_tum.cc:79-96).  When enabled every extract
+ * call records HIP events between its stages on the handle's stream;
+ * orbgpu_extractor_stage_times synchronises and returns the mean milliseconds
+ * of {pyramid, FAST cells, quadtree, blur, describe} over the calls since
+ * profiling was enabled (at most the last 128). */
+int orbgpu_extractor_profile(orbgpu_extractor *e, int32_t enable);
+int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms5, int32_t *ncalls);
+
 /* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:63-83) and the per-level
  * feature quotas mnFeaturesPerLevel.  Any pointer may be NULL. */

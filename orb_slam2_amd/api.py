@@ -31,6 +31,7 @@ MODE_LOCAL_MAP, MODE_LAST_FRAME, MODE_KEYFRAME = 0, 1, 2
 EXPORTS = [
     "orbgpu_last_error", "orbgpu_device_count",
     "orbgpu_extractor_create", "orbgpu_extractor_destroy", "orbgpu_extractor_set_stream", "orbgpu_extractor_sync",
+    "orbgpu_extractor_profile", "orbgpu_extractor_stage_times",
     "orbgpu_extractor_tables", "orbgpu_extractor_max_keypoints", "orbgpu_extract", "orbgpu_extract_batch",
     "orbgpu_extract_batch_device", "orbgpu_pyramid_level", "orbgpu_pyramid_level_device",
     "orbgpu_debug_level_candidates", "orbgpu_debug_level_selected",
@@ -70,6 +71,8 @@ def load_library():
         L.orbgpu_extractor_destroy.restype = None
         L.orbgpu_extractor_set_stream.argtypes = [vp, vp]
         L.orbgpu_extractor_sync.argtypes = [vp]
+        L.orbgpu_extractor_profile.argtypes = [vp, i32]
+        L.orbgpu_extractor_stage_times.argtypes = [vp, vp, C.POINTER(i32)]
         L.orbgpu_extractor_tables.argtypes = [vp, C.POINTER(i32), vp, vp, vp, vp, vp]
         L.orbgpu_extractor_max_keypoints.argtypes = [vp, C.POINTER(i32)]
         L.orbgpu_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
@@ -191,6 +194,15 @@ class ORBextractor:
 
     def sync(self):
         _check(self._lib.orbgpu_extractor_sync(self._h), "orbgpu_extractor_sync")
+
+    def profile(self, enable=True):
+        _check(self._lib.orbgpu_extractor_profile(self._h, int(enable)), "orbgpu_extractor_profile")
+
+    def stage_times(self):
+        """Mean ms of (pyramid, fast_cells, octree, blur, describe) and the number of calls averaged."""
+        ms = np.zeros(5, np.float32); n = C.c_int32()
+        _check(self._lib.orbgpu_extractor_stage_times(self._h, _p(ms), C.byref(n)), "orbgpu_extractor_stage_times")
+        return ms, n.value
 
     # ---- getters (include/ORBextractor.h:63-83) -----------------------------
     def GetLevels(self):

@@ -741,24 +741,35 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     return ORBGPU_OK;
 }
 
-int launch_detect(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, uint32_t *slots, int32_t *cell_counts,
-                  uint32_t *cand, QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count,
-                  int32_t *status)
+int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, uint32_t *slots, int32_t *cell_counts)
 {
     hipLaunchKernelGGL(k_fast_cells, dim3(G.total_cells, nimg), dim3(256), 0, st, pyr, G, slots, cell_counts);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
+                  QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status)
+{
     hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(1024), 0, st, G, slots, cell_counts, cand, nodes, scratch, sel,
                        sel_count, cand_count, status);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
 
-int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G, const uint32_t *sel,
-                    const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
-                    int capacity, int32_t *status)
+int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G)
 {
     int tiles = 0;
     for (int l = 0; l < G.nlevels; l++) tiles += ((G.lv[l].w + kBW - 1) / kBW) * ((G.lv[l].h + kBH - 1) / kBH);
     hipLaunchKernelGGL(k_blur, dim3(tiles, nimg), dim3(256), 0, st, pyr, blur, G);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t *blur, const Geom &G, const uint32_t *sel,
+                    const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
+                    int capacity, int32_t *status)
+{
     hipLaunchKernelGGL(k_describe, dim3((G.total_kp_cap + 3) / 4, nimg), dim3(256), 0, st, pyr, blur, G, sel, sel_count,
                        pattern, kps, desc, counts, capacity, status);
     ORBGPU_HIP_CHECK(hipGetLastError());

@@ -24,10 +24,11 @@ void set_error(const char *fmt, ...)
 
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
                    const Geom &G, const XTab *xtab, const YTab *ytab);
-int launch_detect(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, uint32_t *slots, int32_t *cell_counts,
-                  uint32_t *cand, QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count,
-                  int32_t *status);
-int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G, const uint32_t *sel,
+int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, uint32_t *slots, int32_t *cell_counts);
+int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
+                  QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status);
+int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G);
+int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t *blur, const Geom &G, const uint32_t *sel,
                     const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
                     int capacity, int32_t *status);
 
@@ -78,7 +79,13 @@ struct orbgpu_extractor {
     DevBuf st_img, st_kps, st_desc, st_counts;  // staging for the host entry points
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
+    // optional stage timing: a ring of event sets, one set per extract call
+    bool profile = false;
+    std::vector<hipEvent_t> ev;  // kProfSets * kProfEvents
+    int prof_next = 0, prof_used = 0;
 };
+
+static constexpr int kProfSets = 128, kProfEvents = 6;  // start, pyramid, fast, octree, blur, describe
 
 // ORBextractor::ORBextractor tables (src/ORBextractor.cc:469-512).
 static void compute_tables(orbgpu_extractor *e)
@@ -338,6 +345,7 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e)
                       &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->st_img, &e->st_kps, &e->st_desc, &e->st_counts};
     for (DevBuf *b : bufs) b->release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -353,6 +361,38 @@ int orbgpu_extractor_sync(orbgpu_extractor *e)
 {
     if (!e) return ORBGPU_E_INVALID;
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return ORBGPU_OK;
+}
+
+int orbgpu_extractor_profile(orbgpu_extractor *e, int32_t enable)
+{
+    if (!e) return ORBGPU_E_INVALID;
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    if (enable && e->ev.empty()) {
+        e->ev.resize((size_t)kProfSets * kProfEvents);
+        for (auto &x : e->ev) ORBGPU_HIP_CHECK(hipEventCreate(&x));
+    }
+    e->profile = enable != 0;
+    e->prof_next = 0;
+    e->prof_used = 0;
+    return ORBGPU_OK;
+}
+
+int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms5, int32_t *ncalls)
+{
+    if (!e || !ms5) return ORBGPU_E_INVALID;
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < kProfEvents - 1; i++) ms5[i] = 0.f;
+    for (int s = 0; s < e->prof_used; s++)
+        for (int i = 0; i < kProfEvents - 1; i++) {
+            float t = 0.f;
+            ORBGPU_HIP_CHECK(hipEventElapsedTime(&t, e->ev[(size_t)s * kProfEvents + i], e->ev[(size_t)s * kProfEvents + i + 1]));
+            ms5[i] += t;
+        }
+    if (e->prof_used > 0)
+        for (int i = 0; i < kProfEvents - 1; i++) ms5[i] /= (float)e->prof_used;
+    if (ncalls) *ncalls = e->prof_used;
     return ORBGPU_OK;
 }
 
@@ -396,17 +436,33 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
     if (rc) return rc;
     const Geom &G = e->G;
     hipStream_t st = e->stream;
+    hipEvent_t *ev = nullptr;
+    if (e->profile) {
+        ev = &e->ev[(size_t)e->prof_next * kProfEvents];
+        e->prof_next = (e->prof_next + 1) % kProfSets;
+        if (e->prof_used < kProfSets) e->prof_used++;
+    }
+#define STAGE_MARK(i) do { if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[i], st)); } while (0)
+    STAGE_MARK(0);
     if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, (uint8_t *)e->pyr.p, G, (const XTab *)e->xtab.p,
                              (const YTab *)e->ytab.p)))
         return rc;
-    if ((rc = launch_detect(st, nimg, (const uint8_t *)e->pyr.p, G, (uint32_t *)e->slots.p, (int32_t *)e->cell_counts.p,
-                            (uint32_t *)e->cand.p, (QNode *)e->nodes.p, (int32_t *)e->scratch.p, (uint32_t *)e->sel.p,
-                            (int32_t *)e->sel_count.p, (int32_t *)e->cand_count.p, (int32_t *)e->status.p)))
+    STAGE_MARK(1);
+    if ((rc = launch_fast(st, nimg, (const uint8_t *)e->pyr.p, G, (uint32_t *)e->slots.p, (int32_t *)e->cell_counts.p))) return rc;
+    STAGE_MARK(2);
+    if ((rc = launch_octree(st, nimg, G, (const uint32_t *)e->slots.p, (const int32_t *)e->cell_counts.p, (uint32_t *)e->cand.p,
+                            (QNode *)e->nodes.p, (int32_t *)e->scratch.p, (uint32_t *)e->sel.p, (int32_t *)e->sel_count.p,
+                            (int32_t *)e->cand_count.p, (int32_t *)e->status.p)))
         return rc;
-    if ((rc = launch_describe(st, nimg, (const uint8_t *)e->pyr.p, (uint8_t *)e->blur.p, G, (const uint32_t *)e->sel.p,
+    STAGE_MARK(3);
+    if ((rc = launch_blur(st, nimg, (const uint8_t *)e->pyr.p, (uint8_t *)e->blur.p, G))) return rc;
+    STAGE_MARK(4);
+    if ((rc = launch_describe(st, nimg, (const uint8_t *)e->pyr.p, (const uint8_t *)e->blur.p, G, (const uint32_t *)e->sel.p,
                               (const int32_t *)e->sel_count.p, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts,
                               capacity, (int32_t *)e->status.p)))
         return rc;
+    STAGE_MARK(5);
+#undef STAGE_MARK
     e->last_nimg = nimg;
     return ORBGPU_OK;
 }
