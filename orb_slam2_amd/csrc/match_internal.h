@@ -4,6 +4,13 @@
 
 namespace orbgpu {
 
+constexpr int kTopK = 8;  // cached best candidates per windowed query
+__host__ __device__ inline size_t match_scratch_ints(int q_cap, int t_cap)
+{
+    // topk keys [2*kTopK*q_cap] | cell_start [3080] | gidx,gx,gy,goct,head [t_cap each] | ncand, sel x2, sd x2, nxt, full [q_cap each]
+    return (3080 + 5 * (size_t)t_cap + (2 * kTopK + 7) * (size_t)q_cap + 1) & ~(size_t)1;  // even: the 64-bit keys come first
+}
+
 struct ScaleTab { float s[ORBGPU_MAX_LEVELS]; };
 
 // mode 0..2: ORBGPU_MODE_*; mode 3: SearchForInitialization.
@@ -22,12 +29,23 @@ struct MatchArgs {
     const uint8_t *occupied;
     int32_t *assign;   // [pair][t_cap]
     int32_t *qmatch;   // [pair][q_cap] or null
-    int32_t *scratch;  // [pair][5*q_cap + 2*t_cap]
+    int32_t *scratch;  // [pair][match_scratch_ints(q_cap, t_cap)]
     int32_t th_dist;
     float nnratio;
     int32_t check_orientation;
     int32_t *nmatches;  // [pair]
 };
+
+#ifdef __HIPCC__
+// 256-bit Hamming distance (ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:1710-1727)
+__device__ __forceinline__ int hamming8(const uint32_t (&a)[8], const uint32_t *__restrict__ b)
+{
+    int d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d += __popc(a[k] ^ b[k]);
+    return d;
+}
+#endif
 
 // Frame::ComputeStereoMatches inputs (src/Frame.cc:600-774).
 struct StereoArgs {

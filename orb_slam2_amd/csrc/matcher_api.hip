@@ -191,7 +191,7 @@ static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orb
         set_error("window matcher: invalid sizes or bounds");
         return ORBGPU_E_INVALID;
     }
-    int rc = m->scratch.ensure((size_t)npairs * (5 * (size_t)q_cap + 2 * (size_t)t_cap) * 4);
+    int rc = m->scratch.ensure((size_t)npairs * match_scratch_ints(q_cap, t_cap) * 4);
     if (rc) return rc;
     MatchArgs A;
     A.mode = mode;

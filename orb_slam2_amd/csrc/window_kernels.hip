@@ -1,0 +1,503 @@
+// Windowed (grid-guided) Hamming matching for gfx950 (wave64): the
+// SearchByProjection overloads of Tracking and SearchForInitialization.
+// Reference lines are relative to /root/reference/src/ORB_SLAM2/.
+//
+// Three kernels per batch of (query set, train frame) pairs:
+//   k_grid_build     one workgroup per pair: the 64x48 keypoint grid of the train
+//                    frame (Frame::AssignFeaturesToGrid / PosInGrid,
+//                    src/Frame.cc:270-293, 485-500), stored column-major with the
+//                    keypoint coordinates re-ordered into grid order;
+//   k_window_topk    one wave per query, whole chip: enumerates the window
+//                    (Frame::GetFeaturesInArea, src/Frame.cc:397-474), evaluates
+//                    the Hamming distances and caches the kTopK best candidates;
+//   k_window_resolve one workgroup per pair: reproduces the reference's
+//                    sequential semantics (a train keypoint claimed by an earlier
+//                    query is skipped by later ones) as the fixed point of
+//                    "query i takes its best candidate not claimed by an accepted
+//                    query j < i" -- unique because query i depends on j < i only --
+//                    then the rotation-histogram check.
+// Candidate order inside a window is the reference's (grid column outer, row
+// inner, insertion order in the cell): with column-major cells one window
+// column is a contiguous run of grid entries, and the ordinal of an entry in
+// the concatenated runs is its position in the reference's candidate vector.
+#include "match_internal.h"
+#include "orbgpu_internal.h"
+
+namespace orbgpu {
+
+constexpr int kCells = ORBGPU_GRID_COLS * ORBGPU_GRID_ROWS;
+constexpr unsigned long long kNoKey = ~0ull;
+
+struct Top2 {
+    unsigned long long a, b;  // two smallest keys, a <= b
+};
+__device__ __forceinline__ void top2_push(Top2 &t, unsigned long long k)
+{
+    if (k < t.a) { t.b = t.a; t.a = k; }
+    else if (k < t.b) t.b = k;
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o)
+{
+    const int lo = __shfl_xor((int)(v & 0xFFFFFFFFull), o), hi = __shfl_xor((int)(v >> 32), o);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, shfl_xor_u64(v, o));
+    return v;
+}
+
+// key = distance << 40 | window ordinal << 20 | train index
+__device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 40); }
+__device__ __forceinline__ int key_train(unsigned long long k) { return (int)(k & 0xFFFFFull); }
+
+struct PairCtx {
+    int nq, n2;
+    const orbgpu_wquery *Q;
+    const uint32_t *QD, *TD;
+    const orbgpu_keypoint *K2;
+    const float *UR;
+    const uint8_t *OCC;
+    int32_t *assign, *qmatch;
+    unsigned long long *topk;
+    int32_t *cell_start, *gidx, *goct, *head, *ncand, *sel[2], *sd[2], *nxt, *full;
+    float *gx, *gy;
+    float invW, invH;
+};
+
+__device__ __forceinline__ PairCtx make_ctx(const MatchArgs &A, int pair)
+{
+    PairCtx P;
+    P.nq = A.nq[pair];
+    P.n2 = A.n2[pair];
+    P.Q = A.q + (size_t)pair * A.q_cap;
+    P.QD = (const uint32_t *)(A.qdesc + (size_t)pair * A.q_cap * 32);
+    P.K2 = A.kps2 + (size_t)pair * A.t_cap;
+    P.TD = (const uint32_t *)(A.desc2 + (size_t)pair * A.t_cap * 32);
+    P.UR = A.uright2 ? A.uright2 + (size_t)pair * A.t_cap : nullptr;
+    P.OCC = A.occupied ? A.occupied + (size_t)pair * A.t_cap : nullptr;
+    P.assign = A.assign + (size_t)pair * A.t_cap;
+    P.qmatch = A.qmatch ? A.qmatch + (size_t)pair * A.q_cap : nullptr;
+    int32_t *s = A.scratch + (size_t)pair * match_scratch_ints(A.q_cap, A.t_cap);
+    P.topk = (unsigned long long *)s;  s += 2 * kTopK * (size_t)A.q_cap;
+    P.cell_start = s;                  s += 3080;
+    P.gidx = s;                        s += A.t_cap;
+    P.gx = (float *)s;                 s += A.t_cap;
+    P.gy = (float *)s;                 s += A.t_cap;
+    P.goct = s;                        s += A.t_cap;
+    P.head = s;                        s += A.t_cap;
+    P.ncand = s;                       s += A.q_cap;
+    P.sel[0] = s;                      s += A.q_cap;
+    P.sel[1] = s;                      s += A.q_cap;
+    P.sd[0] = s;                       s += A.q_cap;
+    P.sd[1] = s;                       s += A.q_cap;
+    P.nxt = s;                         s += A.q_cap;
+    P.full = s;
+    P.invW = __fdiv_rn((float)ORBGPU_GRID_COLS, __fsub_rn(A.maxX, A.minX));
+    P.invH = __fdiv_rn((float)ORBGPU_GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+    return P;
+}
+
+// ---------------------------------------------------------------------------
+// grid
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
+{
+    __shared__ int cs[kCells + 1];
+    __shared__ int cursor[kCells];
+    __shared__ int scan_lds[33];
+    const int pair = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x;
+    const PairCtx P = make_ctx(A, pair);
+    const int n2 = P.n2;
+    for (int i = tid; i <= kCells; i += nt_) cs[i] = 0;
+    for (int i = tid; i < kCells; i += nt_) cursor[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += nt_) {
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.minX), P.invW));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.minY), P.invH));
+        if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS) atomicAdd(&cs[px * ORBGPU_GRID_ROWS + py], 1);
+    }
+    __syncthreads();
+    {
+        int carry = 0;
+        for (int b = 0; b < kCells; b += nt_) {
+            const int cidx = b + tid;
+            const int v = cidx < kCells ? cs[cidx] : 0;
+            int total;
+            const int ex = block_scan_excl(v, &total, scan_lds);
+            if (cidx < kCells) cs[cidx] = carry + ex;
+            carry += total;
+        }
+        if (tid == 0) cs[kCells] = carry;
+    }
+    __syncthreads();
+    // fetch-and-add gives an arbitrary in-cell order ...
+    for (int i = tid; i < n2; i += nt_) {
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.minX), P.invW));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.minY), P.invH));
+        if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS) {
+            const int cidx = px * ORBGPU_GRID_ROWS + py;
+            P.gidx[cs[cidx] + atomicAdd(&cursor[cidx], 1)] = i;
+        }
+    }
+    __syncthreads();
+    // ... so restore insertion (ascending index) order inside every cell
+    for (int cidx = tid; cidx < kCells; cidx += nt_) {
+        const int s = cs[cidx], e = cs[cidx + 1];
+        for (int i = s + 1; i < e; i++) {
+            const int v = P.gidx[i];
+            int j = i - 1;
+            while (j >= s && P.gidx[j] > v) { P.gidx[j + 1] = P.gidx[j]; j--; }
+            P.gidx[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i <= kCells; i += nt_) P.cell_start[i] = cs[i];
+    const int ng = cs[kCells];
+    for (int k = tid; k < ng; k += nt_) {
+        const orbgpu_keypoint kp = P.K2[P.gidx[k]];
+        P.gx[k] = kp.x;
+        P.gy[k] = kp.y;
+        P.goct[k] = kp.octave;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// window enumeration (one wave per query)
+// ---------------------------------------------------------------------------
+// Is train keypoint t unavailable to query i given the accepted selections of
+// earlier queries (lists head/nxt built from sel[cur])?
+__device__ __forceinline__ bool claimed_by_earlier(const PairCtx &P, int mode, int cur, int i, int t, int dist)
+{
+    for (int j = P.head[t]; j >= 0; j = P.nxt[j]) {
+        if (j >= i) continue;
+        if (mode == 3) { if (P.sd[cur][j] <= dist) return true; }  // vMatchedDistance[i2] <= dist (src/ORBmatcher.cc:477)
+        else if (mode == 2 || (P.Q[j].flags & 2)) return true;      // the keypoint already holds a map point
+    }
+    return false;
+}
+
+// DYN = false: cache the kTopK best candidates of the window in wk (LDS, sorted)
+// and count the candidates; DYN = true: apply the claims and return the two best.
+template <bool DYN>
+__device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P, int cur, int i, const orbgpu_wquery &q,
+                                            int *wl, int *ws, unsigned long long *wk, Top2 &t2, int &npass)
+{
+    const int lane = lane_id(), mode = A.mode;
+    const float r = q.r;
+    t2.a = t2.b = kNoKey;
+    npass = 0;
+    const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
+    const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
+    const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
+    const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
+    if (c0 >= ORBGPU_GRID_COLS || c1 < 0 || r0 >= ORBGPU_GRID_ROWS || r1 < 0) return;
+    const int ncols = c1 - c0 + 1;
+    int s = 0, len = 0;
+    if (lane < ncols) {
+        s = P.cell_start[(c0 + lane) * ORBGPU_GRID_ROWS + r0];
+        len = P.cell_start[(c0 + lane) * ORBGPU_GRID_ROWS + r1 + 1] - s;
+    }
+    int inc = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    const int total = __shfl(inc, 63);
+    if (total == 0) return;
+    ws[lane] = s;
+    wl[lane + 1] = inc;
+    if (lane == 0) wl[0] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const bool check = (q.minLevel > 0) || (q.maxLevel >= 0);
+    uint32_t qd[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) qd[k] = P.QD[(size_t)i * 8 + k];
+    for (int base = 0; base < total; base += 64) {
+        const int j = base + lane;
+        unsigned long long key = kNoKey;
+        if (j < total) {
+            int lo = 0, hi = ncols - 1;  // column c with wl[c] <= j < wl[c+1]
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (wl[mid] <= j) lo = mid; else hi = mid - 1;
+            }
+            const int k = ws[lo] + (j - wl[lo]);
+            const int oct = P.goct[k];
+            bool ok = true;
+            if (check) {
+                if (oct < q.minLevel) ok = false;
+                if (q.maxLevel >= 0 && oct > q.maxLevel) ok = false;
+            }
+            if (ok && !(fabsf(__fsub_rn(P.gx[k], q.u)) < r && fabsf(__fsub_rn(P.gy[k], q.v)) < r)) ok = false;
+            if (ok) {
+                const int t = P.gidx[k];
+                if (mode != 3) {
+                    if (P.OCC && P.OCC[t]) ok = false;
+                    if (ok && mode != 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
+                }
+                if (ok) {
+                    const int dist = hamming8(qd, P.TD + (size_t)t * 8);
+                    if (!DYN || !claimed_by_earlier(P, mode, cur, i, t, dist))
+                        key = ((unsigned long long)dist << 40) | ((unsigned long long)j << 20) | (unsigned)t;
+                }
+            }
+        }
+        if (DYN) {
+            top2_push(t2, key);
+        } else {
+            npass += __popcll(__ballot(key != kNoKey));
+            for (int rnd = 0; rnd < kTopK; rnd++) {
+                const unsigned long long m = wave_min_u64(key);
+                if (m == kNoKey || m >= wk[kTopK - 1]) break;
+                if (lane == 0) {
+                    int p = kTopK - 1;
+                    while (p > 0 && wk[p - 1] > m) { wk[p] = wk[p - 1]; p--; }
+                    wk[p] = m;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (key == m) key = kNoKey;
+            }
+        }
+    }
+    if (DYN) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long oa = shfl_xor_u64(t2.a, o), ob = shfl_xor_u64(t2.b, o);
+            const unsigned long long m1 = min(t2.a, oa);
+            const unsigned long long m2 = min(max(t2.a, oa), min(t2.b, ob));
+            t2.a = m1;
+            t2.b = m2;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
+{
+    __shared__ int wl[4][65], ws[4][64];
+    __shared__ unsigned long long wk[4][kTopK];
+    const int pair = blockIdx.y, w = threadIdx.x >> 6, lane = lane_id();
+    const int i = blockIdx.x * 4 + w;
+    const PairCtx P = make_ctx(A, pair);
+    if (i >= P.nq) return;
+    if (lane < kTopK) wk[w][lane] = kNoKey;
+    __builtin_amdgcn_wave_barrier();
+    const orbgpu_wquery q = P.Q[i];
+    Top2 t2;
+    int npass = 0;
+    if (q.flags & 1) scan_window<false>(A, P, 0, i, q, wl[w], ws[w], wk[w], t2, npass);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < kTopK) P.topk[(size_t)i * kTopK + lane] = wk[w][lane];
+    if (lane == 0) P.ncand[i] = npass;
+}
+
+// Acceptance rules of the four matchers, given the best two available candidates.
+__device__ __forceinline__ void decide(const MatchArgs &A, const PairCtx &P, unsigned long long b1, unsigned long long b2,
+                                       int &newsel, int &newd)
+{
+    newsel = -1;
+    newd = 0;
+    if (b1 == kNoKey) return;
+    const int best = key_dist(b1), bidx = key_train(b1);
+    bool ok;
+    if (A.mode == 3) {  // src/ORBmatcher.cc:496-499
+        const float best2 = b2 != kNoKey ? (float)key_dist(b2) : 2147483648.0f;
+        ok = best <= ORBGPU_TH_LOW && (float)best < __fmul_rn(best2, A.nnratio);
+    } else {
+        ok = best <= A.th_dist;
+        if (ok && A.mode == 0 && b2 != kNoKey) {  // ratio test only within one pyramid level (src/ORBmatcher.cc:118-121)
+            const int best2 = key_dist(b2), bidx2 = key_train(b2);
+            if (P.K2[bidx].octave == P.K2[bidx2].octave && (float)best > __fmul_rn(A.nnratio, (float)best2)) ok = false;
+        }
+    }
+    if (ok) { newsel = bidx; newd = best; }
+}
+
+__global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
+{
+    __shared__ int wl[16][65], ws[16][64];
+    __shared__ int hist[ORBGPU_HISTO_LENGTH];
+    __shared__ int sh_changed, sh_keep[3], sh_conflict;
+
+    const int pair = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x;
+    const int lane = lane_id(), wid = tid >> 6, nw = nt_ >> 6;
+    const PairCtx P = make_ctx(A, pair);
+    const int nq = P.nq, n2 = P.n2, mode = A.mode;
+    const bool need2 = (mode == 0 || mode == 3);
+
+    for (int i = tid; i < nq; i += nt_) { P.sel[0][i] = -1; P.sd[0][i] = 0; }
+    __syncthreads();
+
+    int cur = 0;
+    for (int it = 0; it <= nq + 1; it++) {
+        for (int i = tid; i < n2; i += nt_) P.head[i] = -1;
+        if (tid == 0) { sh_changed = 0; sh_conflict = 0; }
+        __syncthreads();
+        for (int i = tid; i < nq; i += nt_) {
+            const int s = P.sel[cur][i];
+            if (s >= 0) {
+                const int old = atomicExch(&P.head[s], i);
+                P.nxt[i] = old;
+                if (old >= 0) sh_conflict = 1;
+            }
+        }
+        __syncthreads();
+        // Modes without a second-best test: if the unconstrained bests (state after
+        // the first pass) select no train keypoint twice, no query's best is
+        // claimed by an earlier one, so that state already is the fixed point.
+        if (it == 1 && !sh_conflict && (mode == 1 || mode == 2)) break;
+
+        // cached candidates, one thread per query
+        for (int i = tid; i < nq; i += nt_) {
+            unsigned long long b1 = kNoKey, b2 = kNoKey;
+            int k = 0;
+            for (; k < kTopK; k++) {
+                const unsigned long long key = P.topk[(size_t)i * kTopK + k];
+                if (key == kNoKey) break;
+                if (claimed_by_earlier(P, mode, cur, i, key_train(key), key_dist(key))) continue;
+                if (b1 == kNoKey) { b1 = key; if (!need2) break; }
+                else { b2 = key; break; }
+            }
+            const bool exhausted = (k == kTopK);
+            if (exhausted && P.ncand[i] > kTopK) {
+                P.full[i] = 1;  // the cache cannot decide: rescan the whole window below
+            } else {
+                P.full[i] = 0;
+                int ns, nd;
+                decide(A, P, b1, b2, ns, nd);
+                if (ns != P.sel[cur][i] || nd != P.sd[cur][i]) sh_changed = 1;
+                P.sel[cur ^ 1][i] = ns;
+                P.sd[cur ^ 1][i] = nd;
+            }
+        }
+        __syncthreads();
+        for (int i = wid; i < nq; i += nw) {
+            if (!P.full[i]) continue;
+            Top2 t2;
+            int npass;
+            scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
+            if (lane == 0) {
+                int ns, nd;
+                decide(A, P, t2.a, t2.b, ns, nd);
+                if (ns != P.sel[cur][i] || nd != P.sd[cur][i]) sh_changed = 1;
+                P.sel[cur ^ 1][i] = ns;
+                P.sd[cur ^ 1][i] = nd;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+        const int ch = sh_changed;
+        __syncthreads();
+        if (!ch) break;
+    }
+
+    // ---- outputs + rotation consistency ------------------------------------------
+    int32_t *assign = P.assign;
+    for (int i = tid; i < n2; i += nt_) assign[i] = -1;
+    for (int i = tid; i < ORBGPU_HISTO_LENGTH; i += nt_) hist[i] = 0;
+    if (tid == 0) sh_changed = 0;  // reused as the match counter
+    __syncthreads();
+    const float factor = 1.0f / ORBGPU_HISTO_LENGTH;  // the reference's 1/30 (src/ORBmatcher.cc:434)
+    const bool ori = A.check_orientation && mode != 0;
+    for (int i = tid; i < nq; i += nt_) {
+        const int s = P.sel[cur][i];
+        if (s < 0) continue;
+        atomicMax(&assign[s], i);  // a later selector overwrites (mode 3: steals) an earlier one
+        if (mode != 3) atomicAdd(&sh_changed, 1);
+        if (ori) {
+            float rot = __fsub_rn(P.Q[i].angle, P.K2[s].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == ORBGPU_HISTO_LENGTH) bin = 0;
+            P.nxt[i] = bin;  // the claim lists are no longer needed
+            atomicAdd(&hist[bin], 1);
+        }
+    }
+    __syncthreads();
+    if (mode == 3) {
+        // SearchForInitialization counts a train keypoint once (stolen matches are decremented, :502-506)
+        for (int i = tid; i < n2; i += nt_)
+            if (assign[i] >= 0) atomicAdd(&sh_changed, 1);
+        __syncthreads();
+    }
+    if (ori) {
+        if (tid == 0) {  // ComputeThreeMaxima (src/ORBmatcher.cc:1661-1704)
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < ORBGPU_HISTO_LENGTH; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            sh_keep[0] = i1; sh_keep[1] = i2; sh_keep[2] = i3;
+        }
+        __syncthreads();
+        const int k1 = sh_keep[0], k2 = sh_keep[1], k3 = sh_keep[2];
+        for (int i = tid; i < nq; i += nt_) {
+            const int s = P.sel[cur][i];
+            if (s < 0) continue;
+            const int bin = P.nxt[i];
+            if (bin == k1 || bin == k2 || bin == k3) continue;
+            if (mode == 3) {
+                // only a live match is removed (:551-559); i is the only writer of assign[s] here
+                if (assign[s] == i) { assign[s] = -1; atomicSub(&sh_changed, 1); }
+            } else {
+                // every entry of a losing bin clears its train keypoint and decrements (:1507-1517)
+                assign[s] = -1;
+                atomicSub(&sh_changed, 1);
+            }
+        }
+        __syncthreads();
+    }
+    if (P.qmatch) {
+        for (int i = tid; i < nq; i += nt_) {
+            const int s = P.sel[cur][i];
+            P.qmatch[i] = (s >= 0 && assign[s] == i) ? s : -1;
+        }
+    }
+    if (tid == 0) A.nmatches[pair] = sh_changed;
+}
+
+__global__ __launch_bounds__(256) void k_shift_queries(const orbgpu_keypoint *__restrict__ kps, const int32_t *__restrict__ n,
+                                                       int capacity, float du, float dv, float th, ScaleTab sc, float minX,
+                                                       float minY, float maxX, float maxY, orbgpu_wquery *__restrict__ q)
+{
+    const int pair = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n[pair]) return;
+    const orbgpu_keypoint kp = kps[(size_t)pair * capacity + i];
+    orbgpu_wquery w;
+    w.u = __fadd_rn(kp.x, du);
+    w.v = __fadd_rn(kp.y, dv);
+    w.r = __fmul_rn(th, sc.s[kp.octave]);
+    w.minLevel = kp.octave - 1;
+    w.maxLevel = kp.octave + 1;
+    w.angle = kp.angle;
+    w.ur = -1.0f;
+    const bool inside = !(w.u < minX || w.u > maxX || w.v < minY || w.v > maxY);  // src/ORBmatcher.cc:1424-1427
+    w.flags = inside ? 3 : 0;
+    q[(size_t)pair * capacity + i] = w;
+}
+
+int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
+{
+    hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
+    hipLaunchKernelGGL(k_window_topk, dim3((A.q_cap + 3) / 4, npairs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_window_resolve, dim3(npairs), dim3(1024), 0, st, A);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+int launch_shift_queries(hipStream_t st, int npairs, const orbgpu_keypoint *kps, const int32_t *n, int capacity, float du,
+                         float dv, float th, const ScaleTab &sc, const float *b4, orbgpu_wquery *q)
+{
+    hipLaunchKernelGGL(k_shift_queries, dim3((capacity + 255) / 256, npairs), dim3(256), 0, st, kps, n, capacity, du, dv, th, sc,
+                       b4[0], b4[1], b4[2], b4[3], q);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+}  // namespace orbgpu
