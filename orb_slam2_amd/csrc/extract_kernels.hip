@@ -10,56 +10,82 @@
 namespace orbgpu {
 
 // ---------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------
-
-// Store a pixel of a level and the reflect-101 images of it that fall into the
-// 19 px halo (src/ORBextractor.cc:1567-1586).  Needs w,h >= 2*kEdge+2.
-__device__ __forceinline__ void store_with_halo(uint8_t *in, int pitch, int w, int h, int x, int y, uint8_t v)
-{
-    const int xm = (x >= 1 && x <= kEdge) ? -x : ((x >= w - 1 - kEdge && x <= w - 2) ? 2 * (w - 1) - x : x);
-    const int ym = (y >= 1 && y <= kEdge) ? -y : ((y >= h - 1 - kEdge && y <= h - 2) ? 2 * (h - 1) - y : y);
-    in[(int64_t)y * pitch + x] = v;
-    if (xm != x) in[(int64_t)y * pitch + xm] = v;
-    if (ym != y) {
-        in[(int64_t)ym * pitch + x] = v;
-        if (xm != x) in[(int64_t)ym * pitch + xm] = v;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Pyramid (ORBextractor::ComputePyramid, src/ORBextractor.cc:1528-1592)
 // ---------------------------------------------------------------------------
+// Level 0 = the input image; 16 pixels per thread, 128-bit accesses when the
+// source row is 16-byte aligned.
 __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ img, int stride, size_t frame_stride,
                                                    uint8_t *__restrict__ pyr, Geom G)
 {
     const LevelGeom &g = G.lv[0];
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 16, y = blockIdx.y, f = blockIdx.z;
     if (x >= g.w) return;
-    const uint8_t v = img[(size_t)f * frame_stride + (size_t)y * stride + x];
-    uint8_t *in = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
-    store_with_halo(in, g.pitch, g.w, g.h, x, y, v);
+    const uint8_t *src = img + (size_t)f * frame_stride + (size_t)y * stride + x;
+    uint8_t *dst = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch + x;
+    if (x + 16 <= g.w && ((uintptr_t)src & 15) == 0) {
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+    } else {
+        const int n = min(16, g.w - x);
+        for (int k = 0; k < n; k++) dst[k] = src[k];
+    }
 }
 
 // cv::resize INTER_LINEAR 8UC1 fixed-point arithmetic (called at :1550) from
-// level l-1 into level l, plus the halo of level l.
+// level l-1 into level l; four output pixels per thread, one 32-bit store.
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, Geom G, int level,
                                                     const XTab *__restrict__ xtab, const YTab *__restrict__ ytab)
 {
     const LevelGeom &gd = G.lv[level];
     const LevelGeom &gs = G.lv[level - 1];
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
-    if (dx >= gd.w || dy >= gd.h) return;
-    const XTab xt = xtab[gd.xtab_off + dx];
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, dy = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
+    if (dx0 >= gd.w || dy >= gd.h) return;
     const YTab yt = ytab[gd.ytab_off + dy];
     uint8_t *base = pyr + (int64_t)f * G.pyr_frame_bytes;
     const uint8_t *S = base + interior_off(gs);
     const uint8_t *S0 = S + (int64_t)yt.sy0 * gs.pitch, *S1 = S + (int64_t)yt.sy1 * gs.pitch;
-    const int sx = xt.sx, sx1 = min(sx + 1, gs.w - 1);
-    const int r0 = S0[sx] * xt.a0 + S0[sx1] * xt.a1;
-    const int r1 = S1[sx] * xt.a0 + S1[sx1] * xt.a1;
-    const int v = (((yt.b0 * (r0 >> 4)) >> 16) + ((yt.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-    store_with_halo(base + interior_off(gd), gd.pitch, gd.w, gd.h, dx, dy, (uint8_t)v);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dx = min(dx0 + k, gd.w - 1);
+        const XTab xt = xtab[gd.xtab_off + dx];
+        const int sx = xt.sx, sx1 = min(sx + 1, gs.w - 1);
+        const int r0 = S0[sx] * xt.a0 + S0[sx1] * xt.a1;
+        const int r1 = S1[sx] * xt.a0 + S1[sx1] * xt.a1;
+        const int v = (((yt.b0 * (r0 >> 4)) >> 16) + ((yt.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)v << (8 * k);
+    }
+    // pixels past the row end land in the halo and are rewritten by k_halo
+    *reinterpret_cast<uint32_t *>(base + interior_off(gd) + (int64_t)dy * gd.pitch + dx0) = packed;
+}
+
+// copyMakeBorder(..., 19, BORDER_REFLECT_101) for every level in one launch
+// (:1567-1586): one thread per halo pixel.  The halo of a level is a ring of
+// (w+38)(h+38) - w*h pixels: full rows above and below, 19+19 columns beside.
+__global__ __launch_bounds__(256) void k_halo(uint8_t *__restrict__ pyr, Geom G)
+{
+    const int f = blockIdx.y;
+    int l = 0, t = blockIdx.x * 256 + threadIdx.x;
+    while (true) {
+        const int n = (G.lv[l].w + 2 * kEdge) * (G.lv[l].h + 2 * kEdge) - G.lv[l].w * G.lv[l].h;
+        if (t < n) break;
+        t -= n;
+        if (++l >= G.nlevels) return;
+    }
+    const LevelGeom &g = G.lv[l];
+    const int W2 = g.w + 2 * kEdge, nTop = kEdge * W2;
+    int x, y;
+    if (t < nTop) { y = t / W2 - kEdge; x = t % W2 - kEdge; }
+    else if (t < 2 * nTop) { const int u = t - nTop; y = g.h + u / W2; x = u % W2 - kEdge; }
+    else {
+        const int u = t - 2 * nTop;
+        y = u / (2 * kEdge);
+        const int c = u % (2 * kEdge);
+        x = c < kEdge ? c - kEdge : g.w + (c - kEdge);
+    }
+    const int sx = x < 0 ? -x : (x >= g.w ? 2 * (g.w - 1) - x : x);
+    const int sy = y < 0 ? -y : (y >= g.h ? 2 * (g.h - 1) - y : y);
+    uint8_t *in = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
+    in[(int64_t)y * g.pitch + x] = in[(int64_t)sy * g.pitch + sx];
 }
 
 // ---------------------------------------------------------------------------
@@ -560,12 +586,16 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
 // ---------------------------------------------------------------------------
 // GaussianBlur 7x7, sigma 2, 8-bit fixed point (called at :1502).  All levels
 // in one launch; the 19 px halo of the source supplies the reflect-101 border.
+// Tile = 128 x 32 pixels per 256-thread workgroup; every thread moves and
+// computes four horizontally adjacent pixels (32-bit global accesses, 64-bit
+// LDS accesses for the 16-bit row sums).
 // ---------------------------------------------------------------------------
-constexpr int kBW = 64, kBH = 16;
+constexpr int kBW = 128, kBH = 32;
+constexpr int kBSrcDw = kBW / 4 + 2;  // dwords per staged source row (4 px apron on both sides)
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G)
 {
-    __shared__ uint8_t src[(kBH + 6) * 72];
+    __shared__ uint32_t src[(kBH + 6) * kBSrcDw];
     __shared__ uint16_t hrow[(kBH + 6) * kBW];
     const int f = blockIdx.y, tid = threadIdx.x;
     int l = 0, t = blockIdx.x;
@@ -573,36 +603,61 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         const int n = ((G.lv[l].w + kBW - 1) / kBW) * ((G.lv[l].h + kBH - 1) / kBH);
         if (t < n) break;
         t -= n;
-        l++;
-        if (l >= G.nlevels) return;
+        if (++l >= G.nlevels) return;
     }
     const LevelGeom &g = G.lv[l];
     const int tilesX = (g.w + kBW - 1) / kBW;
     const int ty0 = (t / tilesX) * kBH, tx0 = (t % tilesX) * kBW;
     const int k0 = 18, k1 = 34, k2 = G.gauss_variant ? 48 : 49, k3 = G.gauss_variant ? 56 : 55;
     const uint8_t *in = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
-    // halo reads stay inside the 19 px border as long as the tile overhang is
-    // clamped to the image (columns/rows beyond w,h are never stored).
-    for (int i = tid; i < (kBH + 6) * (kBW + 6); i += 256) {
-        const int r = i / (kBW + 6), cx = i - r * (kBW + 6);
-        const int y = min(ty0 + r - 3, g.h + 2), x = min(tx0 + cx - 3, g.w + 2);
-        src[r * 72 + cx] = in[(int64_t)y * g.pitch + x];
+    // stage rows ty0-3 .. ty0+kBH+2, columns tx0-4 .. tx0+kBW+3 (clamped into the halo)
+    const int xlim = (g.w + 15) & ~3, ylim = g.h + 2;
+    for (int i = tid; i < (kBH + 6) * kBSrcDw; i += 256) {
+        const int r = i / kBSrcDw, c = i - r * kBSrcDw;
+        const int y = min(ty0 + r - 3, ylim), x = min(tx0 - 4 + 4 * c, xlim);
+        src[i] = *reinterpret_cast<const uint32_t *>(in + (int64_t)y * g.pitch + x);
     }
     __syncthreads();
-    for (int i = tid; i < (kBH + 6) * kBW; i += 256) {
-        const int r = i >> 6, cx = i & 63;
-        const uint8_t *s = src + r * 72 + cx;
-        hrow[i] = (uint16_t)(k0 * (s[0] + s[6]) + k1 * (s[1] + s[5]) + k2 * (s[2] + s[4]) + k3 * s[3]);
+    // horizontal pass: 4 outputs from 12 staged bytes
+    for (int i = tid; i < (kBH + 6) * (kBW / 4); i += 256) {
+        const int r = i >> 5, c = i & 31;
+        const uint32_t *sp = src + r * kBSrcDw + c;
+        const uint32_t a = sp[0], b = sp[1], d = sp[2];
+        // p[k] = pixel (4c - 4 + k) of the tile row, k = 0..11; outputs need p[1..10]
+        const int p1 = (a >> 8) & 255, p2 = (a >> 16) & 255, p3 = a >> 24;
+        const int p4 = b & 255, p5 = (b >> 8) & 255, p6 = (b >> 16) & 255, p7 = b >> 24;
+        const int p8 = d & 255, p9 = (d >> 8) & 255, p10 = (d >> 16) & 255;
+        const uint32_t o0 = k0 * (p1 + p7) + k1 * (p2 + p6) + k2 * (p3 + p5) + k3 * p4;
+        const uint32_t o1 = k0 * (p2 + p8) + k1 * (p3 + p7) + k2 * (p4 + p6) + k3 * p5;
+        const uint32_t o2 = k0 * (p3 + p9) + k1 * (p4 + p8) + k2 * (p5 + p7) + k3 * p6;
+        const uint32_t o3 = k0 * (p4 + p10) + k1 * (p5 + p9) + k2 * (p6 + p8) + k3 * p7;
+        *reinterpret_cast<uint2 *>(hrow + r * kBW + 4 * c) = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));
     }
     __syncthreads();
-    const int cx = tid & 63, x = tx0 + cx;
+    // vertical pass: thread = 4 columns x 4 rows
+    const int c = tid & 31, rg = tid >> 5;
+    const int x = tx0 + 4 * c;
     uint8_t *out = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
+    uint2 h[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) h[k] = *reinterpret_cast<const uint2 *>(hrow + (rg * 4 + k) * kBW + 4 * c);
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
-        const int r = (tid >> 6) * 4 + rr, y = ty0 + r;
-        const uint16_t *hp = hrow + r * kBW + cx;
-        const int s = k0 * (hp[0] + hp[6 * kBW]) + k1 * (hp[kBW] + hp[5 * kBW]) + k2 * (hp[2 * kBW] + hp[4 * kBW]) + k3 * hp[3 * kBW];
-        if (x < g.w && y < g.h) out[(int64_t)y * g.pitch + x] = (uint8_t)min((s + 32768) >> 16, 255);
+        const int y = ty0 + rg * 4 + rr;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int v[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const uint32_t wv = (q < 2) ? h[rr + k].x : h[rr + k].y;
+                v[k] = (q & 1) ? (int)(wv >> 16) : (int)(wv & 0xFFFF);
+            }
+            const int s = k0 * (v[0] + v[6]) + k1 * (v[1] + v[5]) + k2 * (v[2] + v[4]) + k3 * v[3];
+            packed |= (uint32_t)min((s + 32768) >> 16, 255) << (8 * q);
+        }
+        // a partial last group spills at most 3 bytes into the unused margin of the blurred plane
+        if (x < g.w && y < g.h) *reinterpret_cast<uint32_t *>(out + (int64_t)y * g.pitch + x) = packed;
     }
 }
 
@@ -732,11 +787,15 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
                    const Geom &G, const XTab *xtab, const YTab *ytab)
 {
     const LevelGeom &g0 = G.lv[0];
-    hipLaunchKernelGGL(k_pyr_copy0, dim3((g0.w + 255) / 256, g0.h, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G);
-    for (int l = 1; l < G.nlevels; l++) {
+    hipLaunchKernelGGL(k_pyr_copy0, dim3((g0.w + 4095) / 4096, g0.h, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G);
+    int halo = 0;
+    for (int l = 0; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
-        hipLaunchKernelGGL(k_pyr_resize, dim3((g.w + 63) / 64, (g.h + 3) / 4, nimg), dim3(256), 0, st, pyr, G, l, xtab, ytab);
+        halo += (g.w + 2 * kEdge) * (g.h + 2 * kEdge) - g.w * g.h;
+        if (l > 0)
+            hipLaunchKernelGGL(k_pyr_resize, dim3((g.w + 255) / 256, (g.h + 3) / 4, nimg), dim3(256), 0, st, pyr, G, l, xtab, ytab);
     }
+    hipLaunchKernelGGL(k_halo, dim3((halo + 255) / 256, nimg), dim3(256), 0, st, pyr, G);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }

@@ -373,17 +373,24 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
             }
         }
         __syncthreads();
-        for (int i = wid; i < nq; i += nw) {
-            if (!P.full[i]) continue;
-            Top2 t2;
-            int npass;
-            scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
-            if (lane == 0) {
-                int ns, nd;
-                decide(A, P, t2.a, t2.b, ns, nd);
-                if (ns != P.sel[cur][i] || nd != P.sd[cur][i]) sh_changed = 1;
-                P.sel[cur ^ 1][i] = ns;
-                P.sd[cur ^ 1][i] = nd;
+        // queries the cache could not decide: each wave takes 64 queries, finds the
+        // flagged ones with one coalesced load + ballot, and rescans their windows
+        for (int base = wid * 64; base < nq; base += nw * 64) {
+            const int fi = base + lane;
+            unsigned long long m = __ballot(fi < nq && P.full[fi] != 0);
+            while (m) {
+                const int i = base + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                Top2 t2;
+                int npass;
+                scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
+                if (lane == 0) {
+                    int ns, nd;
+                    decide(A, P, t2.a, t2.b, ns, nd);
+                    if (ns != P.sel[cur][i] || nd != P.sd[cur][i]) sh_changed = 1;
+                    P.sel[cur ^ 1][i] = ns;
+                    P.sd[cur ^ 1][i] = nd;
+                }
             }
         }
         __syncthreads();
