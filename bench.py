@@ -145,6 +145,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
 
+    wstats = [mt.window_stats(p) for p in range(0, B, max(1, B // 8))]
     kp_mean = float(d_cnt[1:].float().mean().item())
     nm_mean = float(d_nm.float().mean().item())
 
@@ -189,6 +190,7 @@ def main():
             "stages_ms_per_step": dict({n: float(v) for n, v in zip(names, stage_ms)}, match=match_ms),
             "extract_algorithmic_GBps": frame_alg * B / (float(stage_ms.sum()) * 1e-3) / 1e9,
             "gpu_ms_per_step": gpu_ms / args.steps,
+            "window_resolver_iterations_rescans": wstats,
         }
         if args.cpu_frames > 0 and world == 1:
             fps, dt = cpu_baseline(frames, args.cpu_frames)

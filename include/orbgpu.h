@@ -207,6 +207,12 @@ int orbgpu_search_by_projection_batch_device(
     const uint8_t *d_occupied, int32_t *d_assign, int32_t th_dist, float nnratio,
     int32_t check_orientation, int32_t *d_nmatches);
 
+/* Work counters of the last windowed-matching call for one pair: fixed-point
+ * iterations of the sequential-claim resolution and full window rescans (no
+ * counterpart in the reference; for tests and tuning). */
+int orbgpu_debug_window_stats(orbgpu_matcher *m, int32_t pair, int32_t *iterations,
+                              int32_t *rescans);
+
 /* Builds SearchByProjection(Cur, Last) queries on the device from the last
  * frame's keypoints displaced by a known image-plane motion (du, dv): u = x+du,
  * v = y+dv, r = th*scale[octave], levels octave-1..octave+1, all valid and

@@ -37,7 +37,7 @@ EXPORTS = [
     "orbgpu_debug_level_candidates", "orbgpu_debug_level_selected",
     "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync",
     "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
-    "orbgpu_search_by_projection", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
+    "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
     "orbgpu_search_for_initialization", "orbgpu_stereo_match",
 ]
 
@@ -95,6 +95,7 @@ def load_library():
                                                   C.POINTER(i32)]
         L.orbgpu_search_by_projection_batch_device.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp,
                                                                vp, vp, i32, f32, i32, vp]
+        L.orbgpu_debug_window_stats.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
         L.orbgpu_make_shift_queries_device.argtypes = [vp, i32, vp, vp, i32, f32, f32, f32, vp, i32, vp, vp]
         L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                        C.POINTER(i32)]
@@ -311,6 +312,11 @@ class ORBmatcher:
         _check(self._lib.orbgpu_hamming_bruteforce_device(self._h, C.c_void_p(dQ), nq, C.c_void_p(dT), nt,
                                                           C.c_void_p(d_idx), C.c_void_p(d_d1), C.c_void_p(d_d2)),
                "orbgpu_hamming_bruteforce_device")
+
+    def window_stats(self, pair=0):
+        it, rs = C.c_int32(), C.c_int32()
+        _check(self._lib.orbgpu_debug_window_stats(self._h, pair, C.byref(it), C.byref(rs)), "orbgpu_debug_window_stats")
+        return it.value, rs.value
 
     def SearchByProjection(self, mode, queries, qdesc, kps2, desc2, bounds, uright2=None, occupied=None,
                            th_dist=TH_HIGH):

@@ -4,7 +4,7 @@
 
 namespace orbgpu {
 
-constexpr int kTopK = 8;  // cached best candidates per windowed query
+constexpr int kTopK = 16;  // cached best candidates per windowed query
 __host__ __device__ inline size_t match_scratch_ints(int q_cap, int t_cap)
 {
     // topk keys [2*kTopK*q_cap] | cell_start [3080] | gidx,gx,gy,goct,head [t_cap each] | ncand, sel x2, sd x2, nxt, full [q_cap each]
@@ -34,6 +34,7 @@ struct MatchArgs {
     float nnratio;
     int32_t check_orientation;
     int32_t *nmatches;  // [pair]
+    int32_t *stats;     // optional [pair][4]: resolver iterations, window rescans
 };
 
 #ifdef __HIPCC__

@@ -51,6 +51,8 @@ struct orbgpu_matcher {
     hipStream_t own_stream = nullptr, stream = nullptr;
     MBuf part;     // brute-force partial results
     MBuf scratch;  // window matcher scratch
+    MBuf stats;    // resolver statistics of the last window call
+    int stats_pairs = 0;
     MBuf stage[12];  // staging for the host entry points
 };
 
@@ -107,6 +109,7 @@ void orbgpu_matcher_destroy(orbgpu_matcher *m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->part.release();
     m->scratch.release();
+    m->stats.release();
     for (auto &b : m->stage) b.release();
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
@@ -200,7 +203,23 @@ static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orb
     A.minX = b4[0]; A.minY = b4[1]; A.maxX = b4[2]; A.maxY = b4[3];
     A.occupied = d_occ; A.assign = d_assign; A.qmatch = d_qmatch; A.scratch = (int32_t *)m->scratch.p;
     A.th_dist = th_dist; A.nnratio = nnratio; A.check_orientation = ori; A.nmatches = d_nmatches;
+    if ((rc = m->stats.ensure((size_t)npairs * 16))) return rc;
+    ORBGPU_HIP_CHECK(hipMemsetAsync(m->stats.p, 0, (size_t)npairs * 16, m->stream));
+    A.stats = (int32_t *)m->stats.p;
+    m->stats_pairs = npairs;
     return launch_match_window(m->stream, A, npairs);
+}
+
+int orbgpu_debug_window_stats(orbgpu_matcher *m, int32_t pair, int32_t *iterations, int32_t *rescans)
+{
+    if (!m || pair < 0 || pair >= m->stats_pairs) return ORBGPU_E_INVALID;
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(m->stream));
+    int32_t v[4];
+    ORBGPU_HIP_CHECK(hipMemcpy(v, (int32_t *)m->stats.p + 4 * pair, 16, hipMemcpyDeviceToHost));
+    if (iterations) *iterations = v[0];
+    if (rescans) *rescans = v[1];
+    return ORBGPU_OK;
 }
 
 int orbgpu_search_by_projection_batch_device(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orbgpu_wquery *d_q,

@@ -167,14 +167,16 @@ __global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
 // window enumeration (one wave per query)
 // ---------------------------------------------------------------------------
 // Is train keypoint t unavailable to query i given the accepted selections of
-// earlier queries (lists head/nxt built from sel[cur])?
+// earlier queries?  SearchByProjection: head[t] = lowest index of an accepted
+// query whose match marks t occupied (the keypoint then holds a map point).
+// SearchForInitialization: head/nxt = list of the accepted selectors of t; t is
+// skipped when an earlier selector matched it at a distance <= dist
+// (vMatchedDistance[i2] <= dist, src/ORBmatcher.cc:477).
 __device__ __forceinline__ bool claimed_by_earlier(const PairCtx &P, int mode, int cur, int i, int t, int dist)
 {
-    for (int j = P.head[t]; j >= 0; j = P.nxt[j]) {
-        if (j >= i) continue;
-        if (mode == 3) { if (P.sd[cur][j] <= dist) return true; }  // vMatchedDistance[i2] <= dist (src/ORBmatcher.cc:477)
-        else if (mode == 2 || (P.Q[j].flags & 2)) return true;      // the keypoint already holds a map point
-    }
+    if (mode != 3) return P.head[t] < i;
+    for (int j = P.head[t]; j >= 0; j = P.nxt[j])
+        if (j < i && P.sd[cur][j] <= dist) return true;
     return false;
 }
 
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
 {
     __shared__ int wl[16][65], ws[16][64];
     __shared__ int hist[ORBGPU_HISTO_LENGTH];
-    __shared__ int sh_changed, sh_keep[3], sh_conflict;
+    __shared__ int sh_changed, sh_keep[3];
 
     const int pair = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x;
     const int lane = lane_id(), wid = tid >> 6, nw = nt_ >> 6;
@@ -330,37 +332,45 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
     for (int i = tid; i < nq; i += nt_) { P.sel[0][i] = -1; P.sd[0][i] = 0; }
     __syncthreads();
 
-    int cur = 0;
+    int cur = 0, n_iter = 0, n_full = 0;
     for (int it = 0; it <= nq + 1; it++) {
-        for (int i = tid; i < n2; i += nt_) P.head[i] = -1;
-        if (tid == 0) { sh_changed = 0; sh_conflict = 0; }
+        n_iter++;
+        for (int i = tid; i < n2; i += nt_) P.head[i] = (mode == 3) ? -1 : 0x7FFFFFFF;
+        if (tid == 0) sh_changed = 0;
         __syncthreads();
         for (int i = tid; i < nq; i += nt_) {
             const int s = P.sel[cur][i];
-            if (s >= 0) {
-                const int old = atomicExch(&P.head[s], i);
-                P.nxt[i] = old;
-                if (old >= 0) sh_conflict = 1;
-            }
+            if (s < 0) continue;
+            if (mode == 3) P.nxt[i] = atomicExch(&P.head[s], i);
+            else if (mode == 2 || (P.Q[i].flags & 2)) atomicMin(&P.head[s], i);
         }
         __syncthreads();
-        // Modes without a second-best test: if the unconstrained bests (state after
-        // the first pass) select no train keypoint twice, no query's best is
-        // claimed by an earlier one, so that state already is the fixed point.
-        if (it == 1 && !sh_conflict && (mode == 1 || mode == 2)) break;
 
-        // cached candidates, one thread per query
+        // cached candidates, one thread per query: fetch all keys, then all claim
+        // words (independent loads), then pick the first one or two survivors
         for (int i = tid; i < nq; i += nt_) {
-            unsigned long long b1 = kNoKey, b2 = kNoKey;
-            int k = 0;
-            for (; k < kTopK; k++) {
-                const unsigned long long key = P.topk[(size_t)i * kTopK + k];
-                if (key == kNoKey) break;
-                if (claimed_by_earlier(P, mode, cur, i, key_train(key), key_dist(key))) continue;
-                if (b1 == kNoKey) { b1 = key; if (!need2) break; }
-                else { b2 = key; break; }
+            unsigned long long key[kTopK];
+            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(P.topk + (size_t)i * kTopK);
+#pragma unroll
+            for (int k = 0; k < kTopK / 2; k++) {
+                const ulonglong2 v = kp[k];
+                key[2 * k] = v.x;
+                key[2 * k + 1] = v.y;
             }
-            const bool exhausted = (k == kTopK);
+            bool gone[kTopK];
+#pragma unroll
+            for (int k = 0; k < kTopK; k++)
+                gone[k] = key[k] != kNoKey && claimed_by_earlier(P, mode, cur, i, key_train(key[k]), key_dist(key[k]));
+            unsigned long long b1 = kNoKey, b2 = kNoKey;
+            bool exhausted = true;  // all kTopK entries valid and still undecided
+#pragma unroll
+            for (int k = 0; k < kTopK; k++) {
+                if (!exhausted) continue;
+                if (key[k] == kNoKey) { exhausted = false; continue; }
+                if (gone[k]) continue;
+                if (b1 == kNoKey) { b1 = key[k]; if (!need2) exhausted = false; }
+                else { b2 = key[k]; exhausted = false; }
+            }
             if (exhausted && P.ncand[i] > kTopK) {
                 P.full[i] = 1;  // the cache cannot decide: rescan the whole window below
             } else {
@@ -381,6 +391,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
             while (m) {
                 const int i = base + __ffsll((long long)m) - 1;
                 m &= m - 1;
+                n_full++;
                 Top2 t2;
                 int npass;
                 scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
@@ -467,6 +478,10 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
         }
     }
     if (tid == 0) A.nmatches[pair] = sh_changed;
+    if (A.stats && lane == 0) {
+        if (tid == 0) A.stats[4 * pair] = n_iter;
+        atomicAdd(&A.stats[4 * pair + 1], n_full);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_shift_queries(const orbgpu_keypoint *__restrict__ kps, const int32_t *__restrict__ n,
