@@ -12,6 +12,53 @@ namespace orbgpu {
 // ---------------------------------------------------------------------------
 // Pyramid (ORBextractor::ComputePyramid, src/ORBextractor.cc:1528-1592)
 // ---------------------------------------------------------------------------
+// Store pixels x0 .. x0+n-1 of one row (packed little-endian in v[], NW words).
+template <int NW>
+__device__ __forceinline__ void store_row_span(uint8_t *row, int x0, int n, const uint32_t (&v)[NW])
+{
+    if (n == NW * 4) {
+        if (NW == 4) *reinterpret_cast<uint4 *>(row + x0) = make_uint4(v[0], v[NW > 1 ? 1 : 0], v[NW > 2 ? 2 : 0], v[NW > 3 ? 3 : 0]);
+        else *reinterpret_cast<uint32_t *>(row + x0) = v[0];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NW * 4; k++)
+            if (k < n) row[x0 + k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+    }
+}
+
+// A span of a level plus its reflect-101 image in the halo rows above/below
+// (copyMakeBorder BORDER_REFLECT_101, src/ORBextractor.cc:1567-1586); the halo
+// columns are filled by k_halo_sides.  Needs h >= 2*kEdge+2.
+template <int NW>
+__device__ __forceinline__ void store_span_with_halo(uint8_t *in, int pitch, int w, int h, int x0, int y, int n,
+                                                     const uint32_t (&v)[NW])
+{
+    store_row_span<NW>(in + (int64_t)y * pitch, x0, n, v);
+    const int ym = (y >= 1 && y <= kEdge) ? -y : ((y >= h - 1 - kEdge && y <= h - 2) ? 2 * (h - 1) - y : y);
+    if (ym != y) store_row_span<NW>(in + (int64_t)ym * pitch, x0, n, v);
+}
+
+// Left/right halo columns of every level and every row (halo rows included),
+// one thread per pixel, all levels in one launch.
+__global__ __launch_bounds__(256) void k_halo_sides(uint8_t *__restrict__ pyr, Geom G)
+{
+    const int f = blockIdx.y;
+    int l = 0, b = blockIdx.x;  // a workgroup = 4 rows (38 columns padded to 64 lanes) of one level
+    while (true) {
+        const int n = (G.lv[l].h + 2 * kEdge + 3) >> 2;
+        if (b < n) break;
+        b -= n;
+        if (++l >= G.nlevels) return;
+    }
+    const LevelGeom &g = G.lv[l];
+    const int c = threadIdx.x & 63, y = b * 4 + (threadIdx.x >> 6) - kEdge;
+    if (c >= 2 * kEdge || y >= g.h + kEdge) return;
+    const int x = c < kEdge ? c - kEdge : g.w + (c - kEdge);
+    const int sx = x < 0 ? -x : 2 * (g.w - 1) - x;
+    uint8_t *row = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch;
+    row[x] = row[sx];
+}
+
 // Level 0 = the input image; 16 pixels per thread, 128-bit accesses when the
 // source row is 16-byte aligned.
 __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ img, int stride, size_t frame_stride,
@@ -21,13 +68,17 @@ __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ i
     const int x = (blockIdx.x * 256 + threadIdx.x) * 16, y = blockIdx.y, f = blockIdx.z;
     if (x >= g.w) return;
     const uint8_t *src = img + (size_t)f * frame_stride + (size_t)y * stride + x;
-    uint8_t *dst = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch + x;
-    if (x + 16 <= g.w && ((uintptr_t)src & 15) == 0) {
-        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+    const int n = min(16, g.w - x);
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (n == 16 && ((uintptr_t)src & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(src);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
-        const int n = min(16, g.w - x);
-        for (int k = 0; k < n; k++) dst[k] = src[k];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < n) v[k >> 2] |= (uint32_t)src[k] << (8 * (k & 3));
     }
+    store_span_with_halo<4>(pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g), g.pitch, g.w, g.h, x, y, n, v);
 }
 
 // cv::resize INTER_LINEAR 8UC1 fixed-point arithmetic (called at :1550) from
@@ -43,7 +94,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
     uint8_t *base = pyr + (int64_t)f * G.pyr_frame_bytes;
     const uint8_t *S = base + interior_off(gs);
     const uint8_t *S0 = S + (int64_t)yt.sy0 * gs.pitch, *S1 = S + (int64_t)yt.sy1 * gs.pitch;
-    uint32_t packed = 0;
+    uint32_t v[1] = {0};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int dx = min(dx0 + k, gd.w - 1);
@@ -51,41 +102,10 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
         const int sx = xt.sx, sx1 = min(sx + 1, gs.w - 1);
         const int r0 = S0[sx] * xt.a0 + S0[sx1] * xt.a1;
         const int r1 = S1[sx] * xt.a0 + S1[sx1] * xt.a1;
-        const int v = (((yt.b0 * (r0 >> 4)) >> 16) + ((yt.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)v << (8 * k);
+        const int px = (((yt.b0 * (r0 >> 4)) >> 16) + ((yt.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v[0] |= (uint32_t)px << (8 * k);
     }
-    // pixels past the row end land in the halo and are rewritten by k_halo
-    *reinterpret_cast<uint32_t *>(base + interior_off(gd) + (int64_t)dy * gd.pitch + dx0) = packed;
-}
-
-// copyMakeBorder(..., 19, BORDER_REFLECT_101) for every level in one launch
-// (:1567-1586): one thread per halo pixel.  The halo of a level is a ring of
-// (w+38)(h+38) - w*h pixels: full rows above and below, 19+19 columns beside.
-__global__ __launch_bounds__(256) void k_halo(uint8_t *__restrict__ pyr, Geom G)
-{
-    const int f = blockIdx.y;
-    int l = 0, t = blockIdx.x * 256 + threadIdx.x;
-    while (true) {
-        const int n = (G.lv[l].w + 2 * kEdge) * (G.lv[l].h + 2 * kEdge) - G.lv[l].w * G.lv[l].h;
-        if (t < n) break;
-        t -= n;
-        if (++l >= G.nlevels) return;
-    }
-    const LevelGeom &g = G.lv[l];
-    const int W2 = g.w + 2 * kEdge, nTop = kEdge * W2;
-    int x, y;
-    if (t < nTop) { y = t / W2 - kEdge; x = t % W2 - kEdge; }
-    else if (t < 2 * nTop) { const int u = t - nTop; y = g.h + u / W2; x = u % W2 - kEdge; }
-    else {
-        const int u = t - 2 * nTop;
-        y = u / (2 * kEdge);
-        const int c = u % (2 * kEdge);
-        x = c < kEdge ? c - kEdge : g.w + (c - kEdge);
-    }
-    const int sx = x < 0 ? -x : (x >= g.w ? 2 * (g.w - 1) - x : x);
-    const int sy = y < 0 ? -y : (y >= g.h ? 2 * (g.h - 1) - y : y);
-    uint8_t *in = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
-    in[(int64_t)y * g.pitch + x] = in[(int64_t)sy * g.pitch + sx];
+    store_span_with_halo<1>(base + interior_off(gd), gd.pitch, gd.w, gd.h, dx0, dy, min(4, gd.w - dx0), v);
 }
 
 // ---------------------------------------------------------------------------
@@ -687,6 +707,31 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+// sin and cos of a float angle in [0, 2*pi], evaluated in double (error below one
+// double ulp) and rounded to float -- the correctly rounded float result except
+// in vanishingly rare near-tie cases, i.e. what a good libm sinf/cosf returns.
+// Quadrant reduction with a two-part pi/2, then the classic degree-13/14
+// minimax kernels on |r| <= pi/4.
+__device__ __forceinline__ void sincos_rounded(float x, float *s, float *c)
+{
+    const double xd = (double)x;
+    const double k = rint(xd * 6.36619772367581382433e-01);
+    double r = __fma_rn(-k, 1.57079632673412561417e+00, xd);
+    r = __fma_rn(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double sr = r + r * z * ps;
+    const double cr = 1.0 - 0.5 * z + z * z * pc;
+    const int q = (int)k & 3;
+    const double sv = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
+    const double cv = (q == 0) ? cr : (q == 1) ? -sr : (q == 2) ? -cr : sr;
+    *s = (float)sv;
+    *c = (float)cv;
+}
+
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, Geom G,
@@ -748,7 +793,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     // steered BRIEF on the blurred level
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
     const float ang = __fmul_rn(angle, factorPI);
-    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    float a, b;
+    sincos_rounded(ang, &b, &a);
     const uint8_t *bl = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch + x;
     uint64_t bits[4];
 #pragma unroll
@@ -788,14 +834,13 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
 {
     const LevelGeom &g0 = G.lv[0];
     hipLaunchKernelGGL(k_pyr_copy0, dim3((g0.w + 4095) / 4096, g0.h, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G);
-    int halo = 0;
-    for (int l = 0; l < G.nlevels; l++) {
+    int rows = (g0.h + 2 * kEdge + 3) / 4;
+    for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
-        halo += (g.w + 2 * kEdge) * (g.h + 2 * kEdge) - g.w * g.h;
-        if (l > 0)
-            hipLaunchKernelGGL(k_pyr_resize, dim3((g.w + 255) / 256, (g.h + 3) / 4, nimg), dim3(256), 0, st, pyr, G, l, xtab, ytab);
+        rows += (g.h + 2 * kEdge + 3) / 4;
+        hipLaunchKernelGGL(k_pyr_resize, dim3((g.w + 255) / 256, (g.h + 3) / 4, nimg), dim3(256), 0, st, pyr, G, l, xtab, ytab);
     }
-    hipLaunchKernelGGL(k_halo, dim3((halo + 255) / 256, nimg), dim3(256), 0, st, pyr, G);
+    hipLaunchKernelGGL(k_halo_sides, dim3(rows, nimg), dim3(256), 0, st, pyr, G);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }

@@ -41,6 +41,11 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     const int lo = __shfl_xor((int)(v & 0xFFFFFFFFull), o), hi = __shfl_xor((int)(v >> 32), o);
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src)
+{
+    const int lo = __shfl((int)(v & 0xFFFFFFFFull), src), hi = __shfl((int)(v >> 32), src);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
 #pragma unroll
@@ -250,17 +255,26 @@ __device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P
         if (DYN) {
             top2_push(t2, key);
         } else {
+            // extract this chunk's candidates in ascending order on a 32-bit key
+            // (distance << 22 | window ordinal; ordinals are unique) and insert
+            // them into the sorted cache
             npass += __popcll(__ballot(key != kNoKey));
+            uint32_t k32 = key == kNoKey ? 0xFFFFFFFFu : ((uint32_t)(key >> 40) << 22) | (uint32_t)((key >> 20) & 0xFFFFFu);
             for (int rnd = 0; rnd < kTopK; rnd++) {
-                const unsigned long long m = wave_min_u64(key);
-                if (m == kNoKey || m >= wk[kTopK - 1]) break;
+                uint32_t m = k32;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+                if (m == 0xFFFFFFFFu) break;
+                const int src = __ffsll((long long)__ballot(k32 == m)) - 1;
+                const unsigned long long mk = shfl_u64(key, src);
+                if (mk >= wk[kTopK - 1]) break;
                 if (lane == 0) {
                     int p = kTopK - 1;
-                    while (p > 0 && wk[p - 1] > m) { wk[p] = wk[p - 1]; p--; }
-                    wk[p] = m;
+                    while (p > 0 && wk[p - 1] > mk) { wk[p] = wk[p - 1]; p--; }
+                    wk[p] = mk;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (key == m) key = kNoKey;
+                if (lane == src) k32 = 0xFFFFFFFFu;
             }
         }
     }
