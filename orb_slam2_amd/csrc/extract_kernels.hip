@@ -262,33 +262,53 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
 __device__ __forceinline__ int qn_count(const QNode &n) { return n.count & 0x7FFFFFFF; }
 __device__ __forceinline__ int qn_buf(const QNode &n) { return (int)((uint32_t)n.count >> 31); }
 
+constexpr int kBigNode = 512;  // nodes above this many points are split by the whole workgroup
+
 struct OctCtx {
-    uint32_t *buf[2];
-    QNode *nl[2];
+    uint32_t *buf0, *buf1;
+    QNode *nl0, *nl1;
     int32_t *S;       // node_cap: positions (in the current list) of the nodes to split
     int32_t *cnt4;    // 4*node_cap: per-S-entry quadrant populations
     int32_t *cbase;   // node_cap: exclusive prefix of non-empty children per S entry
-    int32_t *mark;    // node_cap: 1 where the list node is in S, later survivor rank
+    int32_t *mark;    // node_cap: 1 where the list node is in S
+    int32_t *big;     // node_cap: S entries whose node holds more than kBigNode points
     int *scan_lds;
+    int *lds4;        // 4 LDS counters
+    __device__ __forceinline__ uint32_t *buf(int i) const { return i ? buf1 : buf0; }
+    __device__ __forceinline__ QNode *nl(int i) const { return i ? nl1 : nl0; }
 };
 
-// Count quadrant populations of S[0..nS) (wave per node).
-__device__ void oct_count(const OctCtx &c, int cur, int nS)
+__device__ __forceinline__ int quadrant_of(uint32_t p, int midx, int midy)
 {
-    const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    return (cand_x(p) < midx ? 0 : 1) | (cand_y(p) < midy ? 0 : 2);
+}
+
+// Count quadrant populations of S[0..nS): one wave per small node, the whole
+// workgroup for each big node.  Returns the number of big nodes (c.big).
+__device__ int oct_count(const OctCtx &c, int cur, int nS)
+{
+    const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wid = tid >> 6, nw = nt >> 6;
+    const QNode *nl = c.nl(cur);
+    int nB = 0;
+    for (int b = 0; b < nS; b += nt) {
+        const int e = b + tid;
+        const int flag = (e < nS) ? (qn_count(nl[c.S[e]]) > kBigNode) : 0;
+        int total;
+        const int ex = block_scan_excl(flag, &total, c.scan_lds);
+        if (flag) c.big[nB + ex] = e;
+        nB += total;
+    }
+    __syncthreads();
     for (int e = wid; e < nS; e += nw) {
-        const QNode n = c.nl[cur][c.S[e]];
+        const QNode n = nl[c.S[e]];
         const int cnt = qn_count(n);
-        const uint32_t *pts = c.buf[qn_buf(n)] + n.start;
+        if (cnt > kBigNode) continue;
+        const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
         const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         for (int b = 0; b < cnt; b += 64) {
             const int i = b + lane;
-            int q = -1;
-            if (i < cnt) {
-                const uint32_t p = pts[i];
-                q = (cand_x(p) < midx ? 0 : 1) | (cand_y(p) < midy ? 0 : 2);
-            }
+            const int q = (i < cnt) ? quadrant_of(pts[i], midx, midy) : -1;
             c0 += __popcll(__ballot(q == 0));
             c1 += __popcll(__ballot(q == 1));
             c2 += __popcll(__ballot(q == 2));
@@ -298,15 +318,59 @@ __device__ void oct_count(const OctCtx &c, int cur, int nS)
             c.cnt4[4 * e + 0] = c0; c.cnt4[4 * e + 1] = c1; c.cnt4[4 * e + 2] = c2; c.cnt4[4 * e + 3] = c3;
         }
     }
+    for (int bi = 0; bi < nB; bi++) {
+        const int e = c.big[bi];
+        const QNode n = nl[c.S[e]];
+        const int cnt = qn_count(n);
+        const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
+        const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+        if (tid < 4) c.lds4[tid] = 0;
+        __syncthreads();
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int b = wid * 64; b < cnt; b += nt) {
+            const int i = b + lane;
+            const int q = (i < cnt) ? quadrant_of(pts[i], midx, midy) : -1;
+            c0 += __popcll(__ballot(q == 0));
+            c1 += __popcll(__ballot(q == 1));
+            c2 += __popcll(__ballot(q == 2));
+            c3 += __popcll(__ballot(q == 3));
+        }
+        if (lane == 0) {
+            atomicAdd(&c.lds4[0], c0); atomicAdd(&c.lds4[1], c1); atomicAdd(&c.lds4[2], c2); atomicAdd(&c.lds4[3], c3);
+        }
+        __syncthreads();
+        if (tid < 4) c.cnt4[4 * e + tid] = c.lds4[tid];
+        __syncthreads();
+    }
+    return nB;
 }
 
-// Apply the split of S[0..nS) using cnt4.  Returns (through shared scalars
-// written by the caller's conventions) the new list size, the number of
-// children created and the number of children holding more than one point.
-__device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int *out_size, int *out_children, int *out_expand)
+// Child q (0..3) of node n created by S entry e (ExtractorNode::DivideNode, :606-641).
+__device__ __forceinline__ void emit_child(const OctCtx &c, int cur, const QNode &n, int e, int q, int midx, int midy,
+                                           int k0, int k1, int k2, int k3, int s0, int nchild, int db)
+{
+    const int kq = q == 0 ? k0 : q == 1 ? k1 : q == 2 ? k2 : k3;
+    if (kq <= 0) return;
+    const int before = (q > 0 && k0 > 0) + (q > 1 && k1 > 0) + (q > 2 && k2 > 0);
+    const int created = c.cbase[e] + before;  // creation index within this pass
+    QNode ch;
+    ch.x0 = (q & 1) ? (int16_t)midx : n.x0;
+    ch.x1 = (q & 1) ? n.x1 : (int16_t)midx;
+    ch.y0 = (q & 2) ? (int16_t)midy : n.y0;
+    ch.y1 = (q & 2) ? n.y1 : (int16_t)midy;
+    ch.start = s0 + (q > 0 ? k0 : 0) + (q > 1 ? k1 : 0) + (q > 2 ? k2 : 0);
+    ch.count = kq | (db << 31);
+    c.nl(cur ^ 1)[nchild - 1 - created] = ch;  // push_front: later creations sit nearer the front
+}
+
+// Apply the split of S[0..nS) using cnt4 (nB of them listed in c.big): returns
+// the new list size, the number of children created and the number of children
+// holding more than one point.
+__device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, int *out_size, int *out_children, int *out_expand)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = lane_id(), wid = tid >> 6, nw = nt >> 6;
+    const QNode *nl = c.nl(cur);
     // children prefix + expandable count
     int carry = 0, nexp = 0;
     for (int b = 0; b < nS; b += nt) {
@@ -338,15 +402,16 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int *out_s
         const int keep = (i < size) ? (c.mark[i] == 0) : 0;
         int total;
         const int ex = block_scan_excl(keep, &total, c.scan_lds);
-        if (keep) c.nl[cur ^ 1][nchild + carry + ex] = c.nl[cur][i];
+        if (keep) c.nl(cur ^ 1)[nchild + carry + ex] = nl[i];
         carry += total;
     }
-    // scatter the points and emit the child nodes
+    // scatter the points and emit the child nodes: small nodes, one wave each
     for (int e = wid; e < nS; e += nw) {
-        const QNode n = c.nl[cur][c.S[e]];
+        const QNode n = nl[c.S[e]];
         const int cnt = qn_count(n), sb = qn_buf(n), db = sb ^ 1;
-        const uint32_t *pts = c.buf[sb] + n.start;
-        uint32_t *dst = c.buf[db];
+        if (cnt > kBigNode) continue;
+        const uint32_t *pts = c.buf(sb) + n.start;
+        uint32_t *dst = c.buf(db);
         const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
         const int k0 = c.cnt4[4 * e + 0], k1 = c.cnt4[4 * e + 1], k2 = c.cnt4[4 * e + 2], k3 = c.cnt4[4 * e + 3];
         const int s0 = n.start, s1 = s0 + k0, s2 = s1 + k1, s3 = s2 + k2;
@@ -358,7 +423,7 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int *out_s
             uint32_t p = 0;
             if (i < cnt) {
                 p = pts[i];
-                q = (cand_x(p) < midx ? 0 : 1) | (cand_y(p) < midy ? 0 : 2);
+                q = quadrant_of(p, midx, midy);
             }
             const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
             if (q == 0) dst[s0 + r0 + __popcll(b0 & lt)] = p;
@@ -367,21 +432,38 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int *out_s
             else if (q == 3) dst[s3 + r3 + __popcll(b3 & lt)] = p;
             r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
         }
-        if (lane < 4) {
-            const int kq = lane == 0 ? k0 : lane == 1 ? k1 : lane == 2 ? k2 : k3;
-            if (kq > 0) {
-                const int before = (lane > 0 && k0 > 0) + (lane > 1 && k1 > 0) + (lane > 2 && k2 > 0);
-                const int created = c.cbase[e] + before;  // creation index within this pass
-                QNode ch;
-                ch.x0 = (lane & 1) ? (int16_t)midx : n.x0;
-                ch.x1 = (lane & 1) ? n.x1 : (int16_t)midx;
-                ch.y0 = (lane & 2) ? (int16_t)midy : n.y0;
-                ch.y1 = (lane & 2) ? n.y1 : (int16_t)midy;
-                ch.start = lane == 0 ? s0 : lane == 1 ? s1 : lane == 2 ? s2 : s3;
-                ch.count = kq | (db << 31);
-                c.nl[cur ^ 1][nchild - 1 - created] = ch;  // push_front: later creations sit nearer the front
+        if (lane < 4) emit_child(c, cur, n, e, lane, midx, midy, k0, k1, k2, k3, s0, nchild, db);
+    }
+    // big nodes: the whole workgroup, stable ranks from two packed block scans per 1024 points
+    for (int bi = 0; bi < nB; bi++) {
+        const int e = c.big[bi];
+        if (e >= nS) continue;  // listed by oct_count but outside the prefix being split
+        const QNode n = nl[c.S[e]];
+        const int cnt = qn_count(n), sb = qn_buf(n), db = sb ^ 1;
+        const uint32_t *pts = c.buf(sb) + n.start;
+        uint32_t *dst = c.buf(db);
+        const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+        const int k0 = c.cnt4[4 * e + 0], k1 = c.cnt4[4 * e + 1], k2 = c.cnt4[4 * e + 2], k3 = c.cnt4[4 * e + 3];
+        const int s0 = n.start, s1 = s0 + k0, s2 = s1 + k1, s3 = s2 + k2;
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (int b = 0; b < cnt; b += nt) {
+            const int i = b + tid;
+            int q = -1;
+            uint32_t p = 0;
+            if (i < cnt) {
+                p = pts[i];
+                q = quadrant_of(p, midx, midy);
             }
+            int t01, t23;
+            const int e01 = block_scan_excl((q == 0) | ((q == 1) << 16), &t01, c.scan_lds);
+            const int e23 = block_scan_excl((q == 2) | ((q == 3) << 16), &t23, c.scan_lds);
+            if (q == 0) dst[s0 + r0 + (e01 & 0xFFFF)] = p;
+            else if (q == 1) dst[s1 + r1 + (e01 >> 16)] = p;
+            else if (q == 2) dst[s2 + r2 + (e23 & 0xFFFF)] = p;
+            else if (q == 3) dst[s3 + r3 + (e23 >> 16)] = p;
+            r0 += t01 & 0xFFFF; r1 += t01 >> 16; r2 += t23 & 0xFFFF; r3 += t23 >> 16;
         }
+        if (tid < 4) emit_child(c, cur, n, e, tid, midx, midy, k0, k1, k2, k3, s0, nchild, db);
     }
     __syncthreads();
     *out_size = nchild + (size - nS);
@@ -393,28 +475,45 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
                                                  const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,
                                                  int32_t *scratch, uint32_t *__restrict__ sel,
                                                  int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,
-                                                 int32_t *__restrict__ status)
+                                                 int32_t *__restrict__ status, int keys_cap, int lds_nodes)
 {
+    // dynamic LDS: keys_cap 64-bit sort keys, then (lds_nodes != 0) the node
+    // arrays and per-node work lists of this level -- keeping them on chip takes
+    // a dozen dependent global-memory round trips out of every subdivision round
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(dyn_lds);
     __shared__ int scan_lds[33];
-    __shared__ unsigned long long keys[4096];
     __shared__ int root_cnt[kMaxRoots], root_start[kMaxRoots];
-    __shared__ int sh_a;
+    __shared__ int sh_a, lds4[4];
+    __shared__ int coff[1025];
 
     const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int lane = lane_id(), wid = tid >> 6, nw = nt >> 6;
     const LevelGeom &g = G.lv[level];
     const int N = g.quota;
     OctCtx c;
-    c.buf[0] = cand + (int64_t)f * G.cand_frame_u32 + g.cand_off;
-    c.buf[1] = c.buf[0] + g.cand_cap;
-    c.nl[0] = nodes + (int64_t)f * G.node_frame + g.node_off;
-    c.nl[1] = c.nl[0] + g.node_cap;
+    c.buf0 = cand + (int64_t)f * G.cand_frame_u32 + g.cand_off;
+    c.buf1 = c.buf0 + g.cand_cap;
+    c.nl0 = nodes + (int64_t)f * G.node_frame + g.node_off;
+    c.nl1 = c.nl0 + g.node_cap;
     int32_t *scr = scratch + ((int64_t)f * G.node_frame + g.node_off) * 4;
     c.S = scr;
     c.cnt4 = scr + g.node_cap;
     c.cbase = scr + 5 * g.node_cap;
     c.mark = scr + 6 * g.node_cap;
+    c.big = scr + 7 * g.node_cap;
+    if (lds_nodes) {
+        c.nl0 = reinterpret_cast<QNode *>(dyn_lds + (size_t)keys_cap * 8);
+        c.nl1 = c.nl0 + g.node_cap;
+        int32_t *ip = reinterpret_cast<int32_t *>(c.nl1 + g.node_cap);
+        c.S = ip;
+        c.cnt4 = ip + g.node_cap;
+        c.cbase = ip + 5 * g.node_cap;
+        c.mark = ip + 6 * g.node_cap;
+        c.big = ip + 7 * g.node_cap;
+    }
     c.scan_lds = scan_lds;
+    c.lds4 = lds4;
     int32_t *out_count = sel_count + f * G.nlevels + level;
     uint32_t *out_sel = sel + (int64_t)f * G.total_kp_cap + g.kp_off;
 
@@ -428,7 +527,19 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
         const int cnt = ci < nCells ? cc[ci] : 0;
         int total;
         const int ex = block_scan_excl(cnt, &total, scan_lds);
-        for (int k = 0; k < cnt; k++) c.buf[0][M + ex + k] = sl[(int64_t)ci * g.cell_cap + k];
+        coff[tid] = ex;
+        if (tid == 0) coff[nt] = total;
+        __syncthreads();
+        // one thread per candidate: find its cell by bisection of the offsets
+        for (int j = tid; j < total; j += nt) {
+            int lo = 0, hi = nt - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (coff[mid] <= j) lo = mid; else hi = mid - 1;
+            }
+            c.buf0[M + j] = sl[(int64_t)(b + lo) * g.cell_cap + (j - coff[lo])];
+        }
+        __syncthreads();
         M += total;
     }
     if (tid == 0) cand_count[f * G.nlevels + level] = M;
@@ -451,12 +562,12 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
                 uint32_t p = 0;
                 int flag = 0;
                 if (i < M) {
-                    p = c.buf[0][i];
+                    p = c.buf0[i];
                     flag = ((int)((float)cand_x(p) / hX) == r);
                 }
                 int total;
                 const int ex = block_scan_excl(flag, &total, scan_lds);
-                if (flag) c.buf[1][outpos + ex] = p;
+                if (flag) c.buf1[outpos + ex] = p;
                 outpos += total;
             }
             if (tid == 0) { root_cnt[r] = outpos - start; root_start[r] = start; }
@@ -477,7 +588,7 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
                 n.y1 = (int16_t)(g.h - 2 * kMinBorder);
                 n.start = root_start[r];
                 n.count = root_cnt[r] | (rb << 31);
-                c.nl[0][size] = n;
+                c.nl0[size] = n;
             }
             size++;
         }
@@ -493,7 +604,7 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
         int nS = 0;
         for (int b = 0; b < size; b += nt) {
             const int i = b + tid;
-            const int flag = (i < size) ? (qn_count(c.nl[cur][i]) > 1) : 0;
+            const int flag = (i < size) ? (qn_count(c.nl(cur)[i]) > 1) : 0;
             int total;
             const int ex = block_scan_excl(flag, &total, scan_lds);
             if (flag) c.S[nS + ex] = i;
@@ -501,10 +612,10 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
         }
         __syncthreads();
         if (nS == 0) break;  // nothing can be divided: size == prevSize
-        oct_count(c, cur, nS);
+        const int nB = oct_count(c, cur, nS);
         __syncthreads();
         int nchild, nexp;
-        oct_apply(c, cur, size, nS, &size, &nchild, &nexp);
+        oct_apply(c, cur, size, nS, nB, &size, &nchild, &nexp);
         cur ^= 1;
         if (size >= N || size == prevSize) break;
         if (size + nexp * 3 > N) {
@@ -519,7 +630,7 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
                     const int i = b + tid;
                     int flag = 0, cnt = 0;
                     if (i < lastChildren) {
-                        cnt = qn_count(c.nl[cur][i]);
+                        cnt = qn_count(c.nl(cur)[i]);
                         flag = cnt > 1;
                     }
                     int total;
@@ -547,7 +658,7 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
                 }
                 for (int i = tid; i < nC; i += nt) c.S[i] = lastChildren - 1 - (int)(keys[i] & 0xFFFFFFFFull);
                 __syncthreads();
-                oct_count(c, cur, nC);
+                const int nB2 = oct_count(c, cur, nC);
                 __syncthreads();
                 // first j with size + sum_{i<=j}(children_i - 1) >= N
                 int acc = size, jstar = -1;
@@ -570,7 +681,7 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
                     __syncthreads();
                 }
                 const int nS2 = jstar >= 0 ? jstar + 1 : nC;
-                oct_apply(c, cur, size, nS2, &size, &nchild, &nexp);
+                oct_apply(c, cur, size, nS2, nB2, &size, &nchild, &nexp);
                 cur ^= 1;
                 if (size >= N || size == prev2) { finish = true; break; }
                 lastChildren = nchild;
@@ -583,22 +694,20 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
         if (tid == 0) atomicOr(status, 1);
         size = g.kp_cap;
     }
-    for (int e = wid; e < size; e += nw) {
-        const QNode n = c.nl[cur][e];
+    // eight lanes per node
+    for (int e = (tid >> 3); e < size; e += (nt >> 3)) {
+        const QNode n = c.nl(cur)[e];
         const int cnt = qn_count(n);
-        const uint32_t *pts = c.buf[qn_buf(n)] + n.start;
+        const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
         uint32_t best = 0;
-        for (int b = 0; b < cnt; b += 64) {
-            const int i = b + lane;
-            if (i < cnt) {
-                // highest response, earliest position on ties
-                const uint32_t key = ((uint32_t)cand_s(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i);
-                best = max(best, key);
-            }
+        for (int i = tid & 7; i < cnt; i += 8) {
+            // highest response, earliest position on ties
+            const uint32_t key = ((uint32_t)cand_s(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i);
+            best = max(best, key);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o));
-        if (lane == 0) out_sel[e] = pts[0xFFFFFFu - (best & 0xFFFFFFu)];
+        for (int o = 4; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o));
+        if ((tid & 7) == 0) out_sel[e] = pts[0xFFFFFFu - (best & 0xFFFFFFu)];
     }
     if (tid == 0) *out_count = size;
 }
@@ -732,8 +841,6 @@ __device__ __forceinline__ void sincos_rounded(float x, float *s, float *c)
     *c = (float)cv;
 }
 
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, Geom G,
                                                   const uint32_t *__restrict__ sel, const int32_t *__restrict__ sel_count,
                                                   const int8_t *__restrict__ pattern, orbgpu_keypoint *__restrict__ kps,
@@ -762,25 +869,35 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     const int oi = off + i;
     if (oi >= capacity) return;
 
+    // the sampling pattern does not depend on anything: fetch it first
+    char4 pt[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pt[k] = reinterpret_cast<const char4 *>(pattern)[k * 64 + lane];
     const uint32_t p = sel[(int64_t)f * G.total_kp_cap + slot];
     const int x = cand_x(p) + kMinBorder, y = cand_y(p) + kMinBorder;  // level coordinates (:1129-1130)
     const uint8_t *img = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch + x;
 
-    // intensity centroid over the circular patch: two rows per step
+    // intensity centroid over the circular patch: two rows per step, all 16
+    // loads issued back to back (lanes outside the disc read the centre, weight 0)
     int m10 = 0, m01 = 0;
     {
         const int half = lane >> 5, u = (lane & 31) - 15;
-#pragma unroll 4
+        const unsigned long long umax_nibbles = 0x3689ABCDDEEEFFFFull;  // umax[v] = nibble v: 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3
+        int I[16], wu[16], wv[16];
+#pragma unroll
         for (int r = 0; r < 16; r++) {
             const int v = -15 + 2 * r + half;
-            if (v <= 15 && (lane & 31) < 31) {
-                const int av = v < 0 ? -v : v;
-                if (u >= -c_umax[av] && u <= c_umax[av]) {
-                    const int I = img[(int64_t)v * g.pitch + u];
-                    m10 += u * I;
-                    m01 += v * I;
-                }
-            }
+            const int av = v < 0 ? -v : v;
+            const int um = (int)((umax_nibbles >> (4 * (av & 15))) & 15ull);
+            const bool in = v <= 15 && u >= -um && u <= um;
+            I[r] = img[in ? v * g.pitch + u : 0];
+            wu[r] = in ? u : 0;
+            wv[r] = in ? v : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            m10 += wu[r] * I[r];
+            m01 += wv[r] * I[r];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -790,22 +907,27 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // steered BRIEF on the blurred level
+    // steered BRIEF on the blurred level: 8 taps per lane, loads batched
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
     const float ang = __fmul_rn(angle, factorPI);
     float a, b;
     sincos_rounded(ang, &b, &a);
     const uint8_t *bl = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch + x;
     uint64_t bits[4];
+    int tap0[4], tap1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const char4 pt = reinterpret_cast<const char4 *>(pattern)[k * 64 + lane];
-        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
+        const float x0 = (float)pt[k].x, y0 = (float)pt[k].y, x1 = (float)pt[k].z, y1 = (float)pt[k].w;
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bl[(int64_t)r0 * g.pitch + q0], t1 = bl[(int64_t)r1 * g.pitch + q1];
+        tap0[k] = bl[r0 * g.pitch + q0];
+        tap1[k] = bl[r1 * g.pitch + q1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int t0 = tap0[k], t1 = tap1[k];
         bits[k] = __ballot(t0 < t1);
     }
     if (lane < 4) {
@@ -855,8 +977,17 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, uin
 int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
                   QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status)
 {
-    hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(1024), 0, st, G, slots, cell_counts, cand, nodes, scratch, sel,
-                       sel_count, cand_count, status);
+    int maxcap = 0;
+    for (int l = 0; l < G.nlevels; l++) maxcap = G.lv[l].node_cap > maxcap ? G.lv[l].node_cap : maxcap;
+    int keys_cap = 2;
+    while (keys_cap < maxcap) keys_cap <<= 1;
+    const size_t node_bytes = (size_t)maxcap * (2 * sizeof(QNode) + 8 * sizeof(int32_t));
+    const int lds_nodes = (size_t)keys_cap * 8 + node_bytes <= 56 * 1024;
+    const size_t dyn = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
+    // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several
+    const int threads = nimg * G.nlevels >= 256 ? 256 : 1024;
+    hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch, sel,
+                       sel_count, cand_count, status, keys_cap, lds_nodes);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }

@@ -66,8 +66,10 @@ struct PairCtx {
     const uint8_t *OCC;
     int32_t *assign, *qmatch;
     unsigned long long *topk;
-    int32_t *cell_start, *gidx, *goct, *head, *ncand, *sel[2], *sd[2], *nxt, *full;
-    float *gx, *gy;
+    int32_t *cell_start, *head, *ncand, *sel0, *sel1, *sd0, *sd1, *nxt, *full;
+    const int32_t *sd_cur;  // distances of the current selections (SearchForInitialization claims)
+    int4 *grec;        // grid-ordered train keypoints: {x bits, y bits, octave, index}
+    uint32_t *gdesc;   // grid-ordered train descriptors
     float invW, invH;
 };
 
@@ -87,16 +89,15 @@ __device__ __forceinline__ PairCtx make_ctx(const MatchArgs &A, int pair)
     int32_t *s = A.scratch + (size_t)pair * match_scratch_ints(A.q_cap, A.t_cap);
     P.topk = (unsigned long long *)s;  s += 2 * kTopK * (size_t)A.q_cap;
     P.cell_start = s;                  s += 3080;
-    P.gidx = s;                        s += A.t_cap;
-    P.gx = (float *)s;                 s += A.t_cap;
-    P.gy = (float *)s;                 s += A.t_cap;
-    P.goct = s;                        s += A.t_cap;
+    P.grec = (int4 *)s;                s += 4 * (size_t)A.t_cap;
+    P.gdesc = (uint32_t *)s;           s += 8 * (size_t)A.t_cap;
     P.head = s;                        s += A.t_cap;
     P.ncand = s;                       s += A.q_cap;
-    P.sel[0] = s;                      s += A.q_cap;
-    P.sel[1] = s;                      s += A.q_cap;
-    P.sd[0] = s;                       s += A.q_cap;
-    P.sd[1] = s;                       s += A.q_cap;
+    P.sel0 = s;                        s += A.q_cap;
+    P.sel1 = s;                        s += A.q_cap;
+    P.sd0 = s;                         s += A.q_cap;
+    P.sd1 = s;                         s += A.q_cap;
+    P.sd_cur = P.sd0;
     P.nxt = s;                         s += A.q_cap;
     P.full = s;
     P.invW = __fdiv_rn((float)ORBGPU_GRID_COLS, __fsub_rn(A.maxX, A.minX));
@@ -138,12 +139,13 @@ __global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
     }
     __syncthreads();
     // fetch-and-add gives an arbitrary in-cell order ...
+    int32_t *gidx = P.head;  // free until the resolver runs
     for (int i = tid; i < n2; i += nt_) {
         const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.minX), P.invW));
         const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.minY), P.invH));
         if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS) {
             const int cidx = px * ORBGPU_GRID_ROWS + py;
-            P.gidx[cs[cidx] + atomicAdd(&cursor[cidx], 1)] = i;
+            gidx[cs[cidx] + atomicAdd(&cursor[cidx], 1)] = i;
         }
     }
     __syncthreads();
@@ -151,21 +153,22 @@ __global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
     for (int cidx = tid; cidx < kCells; cidx += nt_) {
         const int s = cs[cidx], e = cs[cidx + 1];
         for (int i = s + 1; i < e; i++) {
-            const int v = P.gidx[i];
+            const int v = gidx[i];
             int j = i - 1;
-            while (j >= s && P.gidx[j] > v) { P.gidx[j + 1] = P.gidx[j]; j--; }
-            P.gidx[j + 1] = v;
+            while (j >= s && gidx[j] > v) { gidx[j + 1] = gidx[j]; j--; }
+            gidx[j + 1] = v;
         }
     }
     __syncthreads();
     for (int i = tid; i <= kCells; i += nt_) P.cell_start[i] = cs[i];
     const int ng = cs[kCells];
     for (int k = tid; k < ng; k += nt_) {
-        const orbgpu_keypoint kp = P.K2[P.gidx[k]];
-        P.gx[k] = kp.x;
-        P.gy[k] = kp.y;
-        P.goct[k] = kp.octave;
+        const int t = gidx[k];
+        const orbgpu_keypoint kp = P.K2[t];
+        P.grec[k] = make_int4(__float_as_int(kp.x), __float_as_int(kp.y), kp.octave, t);
     }
+    // descriptors in grid order: 8 lanes copy one 32-byte descriptor
+    for (int w = tid; w < ng * 8; w += nt_) P.gdesc[w] = P.TD[(size_t)gidx[w >> 3] * 8 + (w & 7)];
 }
 
 // ---------------------------------------------------------------------------
@@ -181,7 +184,7 @@ __device__ __forceinline__ bool claimed_by_earlier(const PairCtx &P, int mode, i
 {
     if (mode != 3) return P.head[t] < i;
     for (int j = P.head[t]; j >= 0; j = P.nxt[j])
-        if (j < i && P.sd[cur][j] <= dist) return true;
+        if (j < i && P.sd_cur[j] <= dist) return true;
     return false;
 }
 
@@ -195,6 +198,7 @@ __device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P
     const float r = q.r;
     t2.a = t2.b = kNoKey;
     npass = 0;
+    int nk = 0;  // valid entries in wk
     const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
     const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
     const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
@@ -232,24 +236,26 @@ __device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P
                 if (wl[mid] <= j) lo = mid; else hi = mid - 1;
             }
             const int k = ws[lo] + (j - wl[lo]);
-            const int oct = P.goct[k];
+            // record and descriptor of grid entry k: independent loads
+            const int4 rec = P.grec[k];
+            const uint4 d0 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k];
+            const uint4 d1 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k + 1];
+            const int oct = rec.z, t = rec.w;
             bool ok = true;
             if (check) {
                 if (oct < q.minLevel) ok = false;
                 if (q.maxLevel >= 0 && oct > q.maxLevel) ok = false;
             }
-            if (ok && !(fabsf(__fsub_rn(P.gx[k], q.u)) < r && fabsf(__fsub_rn(P.gy[k], q.v)) < r)) ok = false;
+            if (ok && !(fabsf(__fsub_rn(__int_as_float(rec.x), q.u)) < r && fabsf(__fsub_rn(__int_as_float(rec.y), q.v)) < r)) ok = false;
+            if (ok && mode != 3) {
+                if (P.OCC && P.OCC[t]) ok = false;
+                if (ok && mode != 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
+            }
             if (ok) {
-                const int t = P.gidx[k];
-                if (mode != 3) {
-                    if (P.OCC && P.OCC[t]) ok = false;
-                    if (ok && mode != 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
-                }
-                if (ok) {
-                    const int dist = hamming8(qd, P.TD + (size_t)t * 8);
-                    if (!DYN || !claimed_by_earlier(P, mode, cur, i, t, dist))
-                        key = ((unsigned long long)dist << 40) | ((unsigned long long)j << 20) | (unsigned)t;
-                }
+                const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
+                                 __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
+                if (!DYN || !claimed_by_earlier(P, mode, cur, i, t, dist))
+                    key = ((unsigned long long)dist << 40) | ((unsigned long long)j << 20) | (unsigned)t;
             }
         }
         if (DYN) {
@@ -267,12 +273,13 @@ __device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P
                 if (m == 0xFFFFFFFFu) break;
                 const int src = __ffsll((long long)__ballot(k32 == m)) - 1;
                 const unsigned long long mk = shfl_u64(key, src);
-                if (mk >= wk[kTopK - 1]) break;
+                if (nk == kTopK && mk >= wk[kTopK - 1]) break;
                 if (lane == 0) {
-                    int p = kTopK - 1;
+                    int p = nk < kTopK ? nk : kTopK - 1;  // keys of one chunk arrive in ascending order: usually a plain append
                     while (p > 0 && wk[p - 1] > mk) { wk[p] = wk[p - 1]; p--; }
                     wk[p] = mk;
                 }
+                if (nk < kTopK) nk++;
                 __builtin_amdgcn_wave_barrier();
                 if (lane == src) k32 = 0xFFFFFFFFu;
             }
@@ -339,21 +346,23 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
 
     const int pair = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x;
     const int lane = lane_id(), wid = tid >> 6, nw = nt_ >> 6;
-    const PairCtx P = make_ctx(A, pair);
+    PairCtx P = make_ctx(A, pair);
     const int nq = P.nq, n2 = P.n2, mode = A.mode;
     const bool need2 = (mode == 0 || mode == 3);
 
-    for (int i = tid; i < nq; i += nt_) { P.sel[0][i] = -1; P.sd[0][i] = 0; }
+    int32_t *selc = P.sel0, *seln = P.sel1, *sdc = P.sd0, *sdn = P.sd1;  // current / next state
+    for (int i = tid; i < nq; i += nt_) { selc[i] = -1; sdc[i] = 0; }
     __syncthreads();
 
-    int cur = 0, n_iter = 0, n_full = 0;
+    const int cur = 0;
+    int n_iter = 0, n_full = 0;
     for (int it = 0; it <= nq + 1; it++) {
         n_iter++;
         for (int i = tid; i < n2; i += nt_) P.head[i] = (mode == 3) ? -1 : 0x7FFFFFFF;
         if (tid == 0) sh_changed = 0;
         __syncthreads();
         for (int i = tid; i < nq; i += nt_) {
-            const int s = P.sel[cur][i];
+            const int s = selc[i];
             if (s < 0) continue;
             if (mode == 3) P.nxt[i] = atomicExch(&P.head[s], i);
             else if (mode == 2 || (P.Q[i].flags & 2)) atomicMin(&P.head[s], i);
@@ -391,9 +400,9 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
                 P.full[i] = 0;
                 int ns, nd;
                 decide(A, P, b1, b2, ns, nd);
-                if (ns != P.sel[cur][i] || nd != P.sd[cur][i]) sh_changed = 1;
-                P.sel[cur ^ 1][i] = ns;
-                P.sd[cur ^ 1][i] = nd;
+                if (ns != selc[i] || nd != sdc[i]) sh_changed = 1;
+                seln[i] = ns;
+                sdn[i] = nd;
             }
         }
         __syncthreads();
@@ -412,14 +421,15 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
                 if (lane == 0) {
                     int ns, nd;
                     decide(A, P, t2.a, t2.b, ns, nd);
-                    if (ns != P.sel[cur][i] || nd != P.sd[cur][i]) sh_changed = 1;
-                    P.sel[cur ^ 1][i] = ns;
-                    P.sd[cur ^ 1][i] = nd;
+                    if (ns != selc[i] || nd != sdc[i]) sh_changed = 1;
+                    seln[i] = ns;
+                    sdn[i] = nd;
                 }
             }
         }
         __syncthreads();
-        cur ^= 1;
+        { int32_t *t1 = selc; selc = seln; seln = t1; int32_t *t2 = sdc; sdc = sdn; sdn = t2; }
+        P.sd_cur = sdc;
         const int ch = sh_changed;
         __syncthreads();
         if (!ch) break;
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
     const float factor = 1.0f / ORBGPU_HISTO_LENGTH;  // the reference's 1/30 (src/ORBmatcher.cc:434)
     const bool ori = A.check_orientation && mode != 0;
     for (int i = tid; i < nq; i += nt_) {
-        const int s = P.sel[cur][i];
+        const int s = selc[i];
         if (s < 0) continue;
         atomicMax(&assign[s], i);  // a later selector overwrites (mode 3: steals) an earlier one
         if (mode != 3) atomicAdd(&sh_changed, 1);
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
         __syncthreads();
         const int k1 = sh_keep[0], k2 = sh_keep[1], k3 = sh_keep[2];
         for (int i = tid; i < nq; i += nt_) {
-            const int s = P.sel[cur][i];
+            const int s = selc[i];
             if (s < 0) continue;
             const int bin = P.nxt[i];
             if (bin == k1 || bin == k2 || bin == k3) continue;
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
     }
     if (P.qmatch) {
         for (int i = tid; i < nq; i += nt_) {
-            const int s = P.sel[cur][i];
+            const int s = selc[i];
             P.qmatch[i] = (s >= 0 && assign[s] == i) ? s : -1;
         }
     }
