@@ -1,0 +1,81 @@
+"""Committed golden fixtures (tests/golden, made by tools/make_golden.py from the oracle).
+
+CPU: the oracle still reproduces them.  GPU: the HIP library reproduces them
+through the C ABI without the oracle in the loop.
+"""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_oracle_reproduces_extraction_goldens(oracle):
+    g = _load("extract_320x240.npz")
+    oe = oracle.Extractor(int(g["params"][0]), float(g["scale"]), int(g["params"][1]), int(g["params"][2]), int(g["params"][3]))
+    for i in range(2):
+        k, d = oe.extract(g["images"][i])
+        assert np.array_equal(k, g["kps%d" % i]) and np.array_equal(d, g["desc%d" % i])
+    g = _load("extract_noise_300x260.npz")
+    on = oracle.Extractor(int(g["params"][0]))
+    k, d = on.extract(g["image"])
+    assert np.array_equal(k, g["kps"]) and np.array_equal(d, g["desc"])
+
+
+def test_oracle_reproduces_match_goldens(oracle):
+    e = _load("extract_320x240.npz"); g = _load("match_320x240.npz")
+    b = np.array([0, 0, 320, 240], np.float32)
+    for mode in (0, 1, 2):
+        n, a = oracle.search_by_projection(mode, g["q%d" % mode], e["desc0"], e["kps1"], e["desc1"], b, th_dist=100,
+                                           nnratio=0.8, checkOri=True)
+        assert n == int(g["n%d" % mode]) and np.array_equal(a, g["assign%d" % mode])
+    prev = np.stack([e["kps0"]["x"], e["kps0"]["y"]], axis=1).astype(np.float32)
+    n, m12, po = oracle.search_for_initialization(e["kps0"], e["desc0"], e["kps1"], e["desc1"], b, prev, 100, 0.9, True)
+    assert n == int(g["init_n"]) and np.array_equal(m12, g["init_m12"]) and np.array_equal(po, g["init_prev"])
+    bi, b1, b2 = oracle.bruteforce(g["bf_Q"], g["bf_T"])
+    assert np.array_equal(bi, g["bf_idx"]) and np.array_equal(b1, g["bf_d1"]) and np.array_equal(b2, g["bf_d2"])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_extraction_goldens():
+    from orb_slam2_amd.api import ORBextractor
+    g = _load("extract_320x240.npz")
+    ex = ORBextractor(int(g["params"][0]), float(g["scale"]), int(g["params"][1]), int(g["params"][2]), int(g["params"][3]),
+                      max_width=320, max_height=240)
+    for i in range(2):
+        k, d = ex(g["images"][i])
+        ref = g["kps%d" % i]
+        assert len(k) == len(ref)
+        for f in ("x", "y", "size", "response", "octave", "class_id"):
+            assert np.array_equal(k[f], ref[f]), f
+        da = np.abs(k["angle"] - ref["angle"])
+        assert np.minimum(da, 360 - da).max() <= np.degrees(1e-4)
+        assert int((d != g["desc%d" % i]).any(axis=1).sum()) <= 0.001 * len(d)
+    g = _load("extract_noise_300x260.npz")
+    ex = ORBextractor(int(g["params"][0]), 1.2, 8, 20, 7, max_width=300, max_height=260)
+    k, d = ex(g["image"])
+    assert np.array_equal(k["x"], g["kps"]["x"]) and np.array_equal(k["y"], g["kps"]["y"])
+    assert np.array_equal(k["response"], g["kps"]["response"]) and np.array_equal(k["octave"], g["kps"]["octave"])
+    assert int((d != g["desc"]).any(axis=1).sum()) <= 0.001 * len(d)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_match_goldens():
+    from orb_slam2_amd.api import ORBmatcher
+    e = _load("extract_320x240.npz"); g = _load("match_320x240.npz")
+    b = np.array([0, 0, 320, 240], np.float32)
+    m = ORBmatcher(0.8, True)
+    for mode in (0, 1, 2):
+        n, a = m.SearchByProjection(mode, g["q%d" % mode], e["desc0"], e["kps1"], e["desc1"], b, th_dist=100)
+        assert n == int(g["n%d" % mode]) and np.array_equal(a, g["assign%d" % mode])
+    m9 = ORBmatcher(0.9, True)
+    prev = np.stack([e["kps0"]["x"], e["kps0"]["y"]], axis=1).astype(np.float32)
+    n, m12, po = m9.SearchForInitialization(e["kps0"], e["desc0"], e["kps1"], e["desc1"], b, prev, 100)
+    assert n == int(g["init_n"]) and np.array_equal(m12, g["init_m12"]) and np.array_equal(po, g["init_prev"])
+    bi, b1, b2 = m9.BruteForce(g["bf_Q"], g["bf_T"])
+    assert np.array_equal(bi, g["bf_idx"]) and np.array_equal(b1, g["bf_d1"]) and np.array_equal(b2, g["bf_d2"])

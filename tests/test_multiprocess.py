@@ -1,0 +1,45 @@
+"""World-size-2 run of the multi-GPU bookkeeping on CPU (gloo): frame sharding,
+barrier and max-over-ranks timing, exactly what bench.py does across GPUs."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from orb_slam2_amd.dist import max_over_ranks, shard_frames, sum_over_ranks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = list(shard_frames(101, world, rank))
+    dist.barrier()
+    elapsed = 1.0 + rank  # rank 1 is the slow one
+    tmax = max_over_ranks(elapsed)
+    total = sum_over_ranks(len(frames))
+    q.put((rank, frames[0], frames[-1], tmax, total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_and_reduce():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, a0, b0, t0, n0), (r1, a1, b1, t1, n1) = res
+    assert (a0, b0, a1, b1) == (0, 50, 51, 100)      # contiguous, disjoint, covering
+    assert t0 == t1 == 2.0                            # the slowest rank's time everywhere
+    assert n0 == n1 == 101.0                          # whole-job frame count

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.npz from the CPU oracle (oracle/liborb_oracle.so).
+
+The reference ships no golden vectors for this path and cannot be built here
+(OpenCV / Eigen / Pangolin / DBoW2 are absent), so these fixtures pin the
+ORACLE's behaviour: a later change to the oracle or to the synthetic image
+generator that alters any output shows up as a fixture mismatch.  Images are
+stored too, so the fixtures do not depend on numpy's random streams.
+
+Usage: python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from orb_slam2_amd import api, synth  # noqa: E402
+
+out = os.path.join(ROOT, "tests", "golden")
+os.makedirs(out, exist_ok=True)
+
+# 1. extraction on two small frames (pyramid checksums, keypoints, descriptors)
+seq = synth.sequence(320, 240, 2, seed=3)
+oe = O.Extractor(500)
+res = [oe.extract(f) for f in seq]
+np.savez_compressed(
+    os.path.join(out, "extract_320x240.npz"), images=seq,
+    kps0=res[0][0], desc0=res[0][1], kps1=res[1][0], desc1=res[1][1],
+    params=np.array([500, 8, 20, 7], np.int32), scale=np.float32(1.2))
+
+# 2. a cropped real-ish stress case: uniform noise (dense corners in every cell)
+rng = np.random.default_rng(4)
+noise = rng.integers(0, 256, (260, 300), dtype=np.uint8)
+on = O.Extractor(300)
+k, d = on.extract(noise)
+np.savez_compressed(os.path.join(out, "extract_noise_300x260.npz"), image=noise, kps=k, desc=d,
+                    params=np.array([300, 8, 20, 7], np.int32), scale=np.float32(1.2))
+
+# 3. matcher vectors on the frames of (1)
+b = np.array([0, 0, 320, 240], np.float32)
+sc = O.tables(oe.p)["scale"]
+q = api.shift_queries(res[0][0], -2.0, -1.0, 15.0, sc, b)
+fix = {}
+for mode in (0, 1, 2):
+    qq = q.copy()
+    if mode == 0:
+        qq["maxLevel"] = res[0][0]["octave"]
+    n, assign = O.search_by_projection(mode, qq.view(O.WQUERY_DTYPE), res[0][1], res[1][0], res[1][1], b, th_dist=100,
+                                       nnratio=0.8, checkOri=True)
+    fix["q%d" % mode] = qq
+    fix["n%d" % mode] = np.int32(n)
+    fix["assign%d" % mode] = assign
+prev = np.stack([res[0][0]["x"], res[0][0]["y"]], axis=1).astype(np.float32)
+n, m12, prev_out = O.search_for_initialization(res[0][0], res[0][1], res[1][0], res[1][1], b, prev, 100, 0.9, True)
+fix.update(init_n=np.int32(n), init_m12=m12, init_prev=prev_out)
+Q = synth.descriptors(300, 5)
+T = synth.descriptors(500, 6)
+T[7] = Q[3]
+bi, b1, b2 = O.bruteforce(Q, T)
+fix.update(bf_Q=Q, bf_T=T, bf_idx=bi, bf_d1=b1, bf_d2=b2)
+np.savez_compressed(os.path.join(out, "match_320x240.npz"), **fix)
+print("golden fixtures written to", out)
