@@ -74,9 +74,8 @@ def main():
     import torch.distributed as dist
     from orb_slam2_amd import api, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from orb_slam2_amd.dist import env_world, max_over_ranks
+    rank, local_rank, world = env_world()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -140,10 +139,7 @@ def main():
     stage_ms, ncalls = ex.stage_times()
     ex.profile(False)
 
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
+    wall_max = max_over_ranks(wall, dev)
 
     wstats = [mt.window_stats(p) for p in range(0, B, max(1, B // 8))]
     kp_mean = float(d_cnt[1:].float().mean().item())

@@ -1,0 +1,48 @@
+// Minimal C++ driver of the drop-in classes: reads two PGM-less raw frames
+// (width height, then w*h bytes each) from a file, extracts ORB features with
+// ORB_SLAM2::ORBextractor and matches them with
+// ORB_SLAM2::ORBmatcher::SearchForInitialization -- the calls Tracking makes
+// (src/Tracking.cc:160-168, 738-748 of the reference) -- and prints a summary.
+//
+// Build: g++ -std=c++14 -Iinclude examples/mono_frontend.cc -Lorb_slam2_amd -lorbgpu -Wl,-rpath,$PWD/orb_slam2_amd
+#include <cstdio>
+#include <cstdlib>
+
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: %s frames.raw\n", argv[0]); return 2; }
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f) { std::perror("open"); return 2; }
+    int wh[2];
+    if (std::fread(wh, sizeof(int), 2, f) != 2) return 2;
+    const int w = wh[0], h = wh[1];
+    std::vector<uint8_t> buf[2];
+    orbcv::Mat im[2];
+    for (int i = 0; i < 2; i++) {
+        buf[i].resize((size_t)w * h);
+        if (std::fread(buf[i].data(), 1, buf[i].size(), f) != buf[i].size()) return 2;
+        im[i] = orbcv::Mat(h, w, buf[i].data(), (size_t)w);
+    }
+    std::fclose(f);
+
+    ORB_SLAM2::ORBextractor extractor(1000, 1.2f, 8, 20, 7, 0, w, h);
+    if (!extractor.Handle()) { std::fprintf(stderr, "extractor: %s\n", extractor.LastError().c_str()); return 1; }
+    std::vector<orbcv::KeyPoint> keys[2];
+    orbcv::Mat desc[2], nomask;
+    for (int i = 0; i < 2; i++) extractor(im[i], nomask, keys[i], desc[i]);
+
+    ORB_SLAM2::ORBmatcher matcher(0.9f, true);
+    std::vector<orbcv::Point2f> prev(keys[0].size());
+    for (size_t i = 0; i < keys[0].size(); i++) prev[i] = keys[0][i].pt;
+    std::vector<int> matches12;
+    const float bounds[4] = {0.f, 0.f, (float)w, (float)h};
+    const int n = matcher.SearchForInitialization(keys[0], desc[0], keys[1], desc[1], bounds, prev, matches12, 100);
+    long sum = 0;
+    for (size_t i = 0; i < matches12.size(); i++) sum = (sum * 31 + (matches12[i] + 2)) % 1000000007L;
+    std::printf("keypoints %zu %zu pyramid0 %dx%d matches %d checksum %ld\n", keys[0].size(), keys[1].size(),
+                extractor.mvImagePyramid[0].cols, extractor.mvImagePyramid[0].rows, n, sum);
+    return 0;
+}
