@@ -43,20 +43,25 @@ __device__ __forceinline__ void store_span_with_halo(uint8_t *in, int pitch, int
 __global__ __launch_bounds__(256) void k_halo_sides(uint8_t *__restrict__ pyr, Geom G)
 {
     const int f = blockIdx.y;
-    int l = 0, b = blockIdx.x;  // a workgroup = 4 rows (38 columns padded to 64 lanes) of one level
+    int l = 0, b = blockIdx.x;  // a workgroup = 16 rows (38 columns padded to 64 lanes) of one level
     while (true) {
-        const int n = (G.lv[l].h + 2 * kEdge + 3) >> 2;
+        const int n = (G.lv[l].h + 2 * kEdge + 15) >> 4;
         if (b < n) break;
         b -= n;
         if (++l >= G.nlevels) return;
     }
     const LevelGeom &g = G.lv[l];
-    const int c = threadIdx.x & 63, y = b * 4 + (threadIdx.x >> 6) - kEdge;
-    if (c >= 2 * kEdge || y >= g.h + kEdge) return;
+    const int c = threadIdx.x & 63, y0 = b * 16 + (threadIdx.x >> 6) * 4 - kEdge;
+    if (c >= 2 * kEdge) return;
     const int x = c < kEdge ? c - kEdge : g.w + (c - kEdge);
     const int sx = x < 0 ? -x : 2 * (g.w - 1) - x;
-    uint8_t *row = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch;
-    row[x] = row[sx];
+    uint8_t *row = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y0 * g.pitch;
+    uint8_t v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = (y0 + r < g.h + kEdge) ? row[(int64_t)r * g.pitch + sx] : 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (y0 + r < g.h + kEdge) row[(int64_t)r * g.pitch + x] = v[r];
 }
 
 // Level 0 = the input image; 16 pixels per thread, 128-bit accesses when the
@@ -82,30 +87,55 @@ __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ i
 }
 
 // cv::resize INTER_LINEAR 8UC1 fixed-point arithmetic (called at :1550) from
-// level l-1 into level l; four output pixels per thread, one 32-bit store.
+// level l-1 into level l.  A thread produces a 4 x 4 block of output pixels (64
+// independent source loads in flight, tap tables amortised over four rows, one
+// 32-bit store per row); the (row group, column group) index is flattened so
+// narrow levels do not leave lanes idle.
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, Geom G, int level,
                                                     const XTab *__restrict__ xtab, const YTab *__restrict__ ytab)
 {
     const LevelGeom &gd = G.lv[level];
     const LevelGeom &gs = G.lv[level - 1];
-    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, dy = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
-    if (dx0 >= gd.w || dy >= gd.h) return;
-    const YTab yt = ytab[gd.ytab_off + dy];
+    const int gx = (gd.w + 3) >> 2, gy = (gd.h + 3) >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (t >= gx * gy) return;
+    const int ry = t / gx, dx0 = (t - ry * gx) * 4, dy0 = ry * 4;
     uint8_t *base = pyr + (int64_t)f * G.pyr_frame_bytes;
     const uint8_t *S = base + interior_off(gs);
-    const uint8_t *S0 = S + (int64_t)yt.sy0 * gs.pitch, *S1 = S + (int64_t)yt.sy1 * gs.pitch;
-    uint32_t v[1] = {0};
+    int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int dx = min(dx0 + k, gd.w - 1);
-        const XTab xt = xtab[gd.xtab_off + dx];
-        const int sx = xt.sx, sx1 = min(sx + 1, gs.w - 1);
-        const int r0 = S0[sx] * xt.a0 + S0[sx1] * xt.a1;
-        const int r1 = S1[sx] * xt.a0 + S1[sx1] * xt.a1;
-        const int px = (((yt.b0 * (r0 >> 4)) >> 16) + ((yt.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        v[0] |= (uint32_t)px << (8 * k);
+        const XTab xt = xtab[gd.xtab_off + min(dx0 + k, gd.w - 1)];
+        sx[k] = xt.sx;
+        sx1[k] = min(xt.sx + 1, gs.w - 1);
+        a0[k] = xt.a0;
+        a1[k] = xt.a1;
     }
-    store_span_with_halo<1>(base + interior_off(gd), gd.pitch, gd.w, gd.h, dx0, dy, min(4, gd.w - dx0), v);
+    YTab yt[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) yt[r] = ytab[gd.ytab_off + min(dy0 + r, gd.h - 1)];
+    uint32_t out[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint8_t *S0 = S + (int64_t)yt[r].sy0 * gs.pitch, *S1 = S + (int64_t)yt[r].sy1 * gs.pitch;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r0 = S0[sx[k]] * a0[k] + S0[sx1[k]] * a1[k];
+            const int r1 = S1[sx[k]] * a0[k] + S1[sx1[k]] * a1[k];
+            const int px = (((yt[r].b0 * (r0 >> 4)) >> 16) + ((yt[r].b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v |= (uint32_t)px << (8 * k);
+        }
+        out[r] = v;
+    }
+    const int n = min(4, gd.w - dx0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (dy0 + r < gd.h) {
+            const uint32_t v[1] = {out[r]};
+            store_span_with_halo<1>(base + interior_off(gd), gd.pitch, gd.w, gd.h, dx0, dy0 + r, n, v);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -956,11 +986,12 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
 {
     const LevelGeom &g0 = G.lv[0];
     hipLaunchKernelGGL(k_pyr_copy0, dim3((g0.w + 4095) / 4096, g0.h, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G);
-    int rows = (g0.h + 2 * kEdge + 3) / 4;
+    int rows = (g0.h + 2 * kEdge + 15) / 16;
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
-        rows += (g.h + 2 * kEdge + 3) / 4;
-        hipLaunchKernelGGL(k_pyr_resize, dim3((g.w + 255) / 256, (g.h + 3) / 4, nimg), dim3(256), 0, st, pyr, G, l, xtab, ytab);
+        rows += (g.h + 2 * kEdge + 15) / 16;
+        hipLaunchKernelGGL(k_pyr_resize, dim3((((g.w + 3) / 4) * ((g.h + 3) / 4) + 255) / 256, nimg), dim3(256), 0, st, pyr, G, l, xtab,
+                           ytab);
     }
     hipLaunchKernelGGL(k_halo_sides, dim3(rows, nimg), dim3(256), 0, st, pyr, G);
     ORBGPU_HIP_CHECK(hipGetLastError());

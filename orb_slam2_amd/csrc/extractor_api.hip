@@ -72,6 +72,8 @@ struct orbgpu_extractor {
     float scale[ORBGPU_MAX_LEVELS], inv_scale[ORBGPU_MAX_LEVELS], sigma2[ORBGPU_MAX_LEVELS], inv_sigma2[ORBGPU_MAX_LEVELS];
     int32_t quota[ORBGPU_MAX_LEVELS];
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t aux_stream = nullptr;          // the blur runs here, beside FAST + quadtree
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     Geom G;
     int geom_w = 0, geom_h = 0;
     int last_nimg = 0;
@@ -85,7 +87,7 @@ struct orbgpu_extractor {
     int prof_next = 0, prof_used = 0;
 };
 
-static constexpr int kProfSets = 128, kProfEvents = 6;  // start, pyramid, fast, octree, blur, describe
+static constexpr int kProfSets = 128, kProfEvents = 7;  // start, pyramid, fast, octree, describe | blur start, blur end (aux stream)
 
 // ORBextractor::ORBextractor tables (src/ORBextractor.cc:469-512).
 static void compute_tables(orbgpu_extractor *e)
@@ -322,6 +324,9 @@ int orbgpu_extractor_create(const orbgpu_params *p, orbgpu_extractor **out)
         if (hipSetDevice(p->device) != hipSuccess) { set_error("hipSetDevice failed"); rc = ORBGPU_E_HIP; break; }
         if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = ORBGPU_E_HIP; break; }
         e->stream = e->own_stream;
+        if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { set_error("aux stream/event creation failed"); rc = ORBGPU_E_HIP; break; }
         if ((rc = e->pattern.ensure(1024))) break;
         if (hipMemcpy(e->pattern.p, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess) { set_error("pattern upload failed"); rc = ORBGPU_E_HIP; break; }
         // validate and size for the largest image up front
@@ -346,6 +351,9 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e)
     for (DevBuf *b : bufs) b->release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
+    if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -383,15 +391,17 @@ int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms5, int32_t *ncall
     if (!e || !ms5) return ORBGPU_E_INVALID;
     ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
-    for (int i = 0; i < kProfEvents - 1; i++) ms5[i] = 0.f;
+    // {pyramid, fast, octree, blur (aux stream), describe (includes waiting for the blur)}
+    static const int from[5] = {0, 1, 2, 5, 3}, to[5] = {1, 2, 3, 6, 4};
+    for (int i = 0; i < 5; i++) ms5[i] = 0.f;
     for (int s = 0; s < e->prof_used; s++)
-        for (int i = 0; i < kProfEvents - 1; i++) {
+        for (int i = 0; i < 5; i++) {
             float t = 0.f;
-            ORBGPU_HIP_CHECK(hipEventElapsedTime(&t, e->ev[(size_t)s * kProfEvents + i], e->ev[(size_t)s * kProfEvents + i + 1]));
+            ORBGPU_HIP_CHECK(hipEventElapsedTime(&t, e->ev[(size_t)s * kProfEvents + from[i]], e->ev[(size_t)s * kProfEvents + to[i]]));
             ms5[i] += t;
         }
     if (e->prof_used > 0)
-        for (int i = 0; i < kProfEvents - 1; i++) ms5[i] /= (float)e->prof_used;
+        for (int i = 0; i < 5; i++) ms5[i] /= (float)e->prof_used;
     if (ncalls) *ncalls = e->prof_used;
     return ORBGPU_OK;
 }
@@ -450,18 +460,26 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
     STAGE_MARK(1);
     if ((rc = launch_fast(st, nimg, (const uint8_t *)e->pyr.p, G, (uint32_t *)e->slots.p, (int32_t *)e->cell_counts.p))) return rc;
     STAGE_MARK(2);
+    // fork: the blur depends on the pyramid only.  FAST keeps every SIMD busy, the
+    // quadtree is latency-bound, so the blur is released after FAST to run beside the quadtree
+    hipStream_t ax = e->aux_stream;
+    ORBGPU_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+    ORBGPU_HIP_CHECK(hipStreamWaitEvent(ax, e->ev_fork, 0));
+    if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], ax));
+    if ((rc = launch_blur(ax, nimg, (const uint8_t *)e->pyr.p, (uint8_t *)e->blur.p, G))) return rc;
+    if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
+    ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
     if ((rc = launch_octree(st, nimg, G, (const uint32_t *)e->slots.p, (const int32_t *)e->cell_counts.p, (uint32_t *)e->cand.p,
                             (QNode *)e->nodes.p, (int32_t *)e->scratch.p, (uint32_t *)e->sel.p, (int32_t *)e->sel_count.p,
                             (int32_t *)e->cand_count.p, (int32_t *)e->status.p)))
         return rc;
     STAGE_MARK(3);
-    if ((rc = launch_blur(st, nimg, (const uint8_t *)e->pyr.p, (uint8_t *)e->blur.p, G))) return rc;
-    STAGE_MARK(4);
+    ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
     if ((rc = launch_describe(st, nimg, (const uint8_t *)e->pyr.p, (const uint8_t *)e->blur.p, G, (const uint32_t *)e->sel.p,
                               (const int32_t *)e->sel_count.p, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts,
                               capacity, (int32_t *)e->status.p)))
         return rc;
-    STAGE_MARK(5);
+    STAGE_MARK(4);
 #undef STAGE_MARK
     e->last_nimg = nimg;
     return ORBGPU_OK;

@@ -338,8 +338,12 @@ __device__ __forceinline__ void decide(const MatchArgs &A, const PairCtx &P, uns
     if (ok) { newsel = bidx; newd = best; }
 }
 
-__global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
+__global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_state)
 {
+    // dynamic LDS (lds_state != 0): selection state, claim words and flags of this
+    // pair, so an iteration of the fixed-point loop touches no global memory except
+    // the (rare) window rescans
+    extern __shared__ __align__(16) int dyn_state[];
     __shared__ int wl[16][65], ws[16][64];
     __shared__ int hist[ORBGPU_HISTO_LENGTH];
     __shared__ int sh_changed, sh_keep[3];
@@ -349,10 +353,62 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
     PairCtx P = make_ctx(A, pair);
     const int nq = P.nq, n2 = P.n2, mode = A.mode;
     const bool need2 = (mode == 0 || mode == 3);
+    if (lds_state) {
+        int32_t *s = dyn_state;
+        P.sel0 = s; s += A.q_cap;
+        P.sel1 = s; s += A.q_cap;
+        P.sd0 = s;  s += A.q_cap;
+        P.sd1 = s;  s += A.q_cap;
+        P.nxt = s;  s += A.q_cap;
+        P.full = s; s += A.q_cap;
+        P.head = s;
+        P.sd_cur = P.sd0;
+    }
 
     int32_t *selc = P.sel0, *seln = P.sel1, *sdc = P.sd0, *sdn = P.sd1;  // current / next state
     for (int i = tid; i < nq; i += nt_) { selc[i] = -1; sdc[i] = 0; }
+    // the cached candidates never change: keep those of the thread's first query in registers
+    unsigned long long key0[kTopK];
+    int ncand0 = 0;
+    if (tid < nq) {
+        const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(P.topk + (size_t)tid * kTopK);
+#pragma unroll
+        for (int k = 0; k < kTopK / 2; k++) {
+            const ulonglong2 v = kp[k];
+            key0[2 * k] = v.x;
+            key0[2 * k + 1] = v.y;
+        }
+        ncand0 = P.ncand[tid];
+    }
     __syncthreads();
+
+    // one query against the current claims: first one or two surviving cached candidates
+    auto evaluate = [&](int i, const unsigned long long (&key)[kTopK], int ncand) {
+        bool gone[kTopK];
+#pragma unroll
+        for (int k = 0; k < kTopK; k++)
+            gone[k] = key[k] != kNoKey && claimed_by_earlier(P, mode, 0, i, key_train(key[k]), key_dist(key[k]));
+        unsigned long long b1 = kNoKey, b2 = kNoKey;
+        bool exhausted = true;  // all kTopK entries valid and still undecided
+#pragma unroll
+        for (int k = 0; k < kTopK; k++) {
+            if (!exhausted) continue;
+            if (key[k] == kNoKey) { exhausted = false; continue; }
+            if (gone[k]) continue;
+            if (b1 == kNoKey) { b1 = key[k]; if (!need2) exhausted = false; }
+            else { b2 = key[k]; exhausted = false; }
+        }
+        if (exhausted && ncand > kTopK) {
+            P.full[i] = 1;  // the cache cannot decide: rescan the whole window below
+        } else {
+            P.full[i] = 0;
+            int ns, nd;
+            decide(A, P, b1, b2, ns, nd);
+            if (ns != selc[i] || nd != sdc[i]) sh_changed = 1;
+            seln[i] = ns;
+            sdn[i] = nd;
+        }
+    };
 
     const int cur = 0;
     int n_iter = 0, n_full = 0;
@@ -368,10 +424,8 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
             else if (mode == 2 || (P.Q[i].flags & 2)) atomicMin(&P.head[s], i);
         }
         __syncthreads();
-
-        // cached candidates, one thread per query: fetch all keys, then all claim
-        // words (independent loads), then pick the first one or two survivors
-        for (int i = tid; i < nq; i += nt_) {
+        if (tid < nq) evaluate(tid, key0, ncand0);
+        for (int i = tid + nt_; i < nq; i += nt_) {
             unsigned long long key[kTopK];
             const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(P.topk + (size_t)i * kTopK);
 #pragma unroll
@@ -380,34 +434,11 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A)
                 key[2 * k] = v.x;
                 key[2 * k + 1] = v.y;
             }
-            bool gone[kTopK];
-#pragma unroll
-            for (int k = 0; k < kTopK; k++)
-                gone[k] = key[k] != kNoKey && claimed_by_earlier(P, mode, cur, i, key_train(key[k]), key_dist(key[k]));
-            unsigned long long b1 = kNoKey, b2 = kNoKey;
-            bool exhausted = true;  // all kTopK entries valid and still undecided
-#pragma unroll
-            for (int k = 0; k < kTopK; k++) {
-                if (!exhausted) continue;
-                if (key[k] == kNoKey) { exhausted = false; continue; }
-                if (gone[k]) continue;
-                if (b1 == kNoKey) { b1 = key[k]; if (!need2) exhausted = false; }
-                else { b2 = key[k]; exhausted = false; }
-            }
-            if (exhausted && P.ncand[i] > kTopK) {
-                P.full[i] = 1;  // the cache cannot decide: rescan the whole window below
-            } else {
-                P.full[i] = 0;
-                int ns, nd;
-                decide(A, P, b1, b2, ns, nd);
-                if (ns != selc[i] || nd != sdc[i]) sh_changed = 1;
-                seln[i] = ns;
-                sdn[i] = nd;
-            }
+            evaluate(i, key, P.ncand[i]);
         }
         __syncthreads();
         // queries the cache could not decide: each wave takes 64 queries, finds the
-        // flagged ones with one coalesced load + ballot, and rescans their windows
+        // flagged ones with one load + ballot, and rescans their windows
         for (int base = wid * 64; base < nq; base += nw * 64) {
             const int fi = base + lane;
             unsigned long long m = __ballot(fi < nq && P.full[fi] != 0);
@@ -532,7 +563,10 @@ int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
 {
     hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(k_window_topk, dim3((A.q_cap + 3) / 4, npairs), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(k_window_resolve, dim3(npairs), dim3(1024), 0, st, A);
+    // selection state in LDS when it fits (6 words per query + 1 per train keypoint)
+    const size_t state = (6 * (size_t)A.q_cap + (size_t)A.t_cap) * 4;
+    const int lds_state = state <= 48 * 1024;
+    hipLaunchKernelGGL(k_window_resolve, dim3(npairs), dim3(1024), lds_state ? state : 0, st, A, lds_state);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
