@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
 // One workgroup per (cell, frame).  Output: per-cell ordered list of packed
 // candidates in a fixed-capacity slot + the count.
 // ---------------------------------------------------------------------------
-constexpr int kTP = 68;  // LDS tile pitch
+constexpr int kTP = 72;  // LDS tile pitch in bytes (18 dwords: a 66 px row + up to 3 bytes of alignment slack)
 
 // Strength A of the best 9-long arc: max over the 16 arcs of the minimum
 // signed contrast, both polarities.  A pixel is a FAST corner at threshold t
@@ -172,11 +172,15 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
     return best;
 }
 
+// i / d for 0 <= i < 4096, 1 <= d <= 66, with m = ceil(2^20 / d)
+__device__ __forceinline__ int div_small(int i, int m) { return (int)(((unsigned)i * (unsigned)m) >> 20); }
+
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G,
                                                     uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts)
 {
-    __shared__ uint8_t tile[kMaxTile * kTP];
-    __shared__ uint8_t score[(kMaxTile - 4) * kTP];  // interior + 1 px zero border
+    __shared__ __align__(16) uint8_t tile[kMaxTile * kTP];
+    __shared__ __align__(16) uint8_t score[(kMaxTile - 4) * kTP];  // interior + 1 px zero border
+    __shared__ __align__(16) uint8_t flag[(kMaxTile - 6) * (kMaxTile - 6) + 16];  // row-major over the interior
     __shared__ uint16_t queue[(kMaxTile - 6) * (kMaxTile - 6)];
     __shared__ int qn;
     __shared__ int scan_lds[33];
@@ -200,75 +204,90 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
         if (tid == 0) *cnt_out = 0;
         return;
     }
-    const uint8_t *src = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)iniY * g.pitch + iniX;
-    for (int i = tid; i < cw * ch; i += 256) {
-        const int ty = i / cw, tx = i - ty * cw;
-        tile[ty * kTP + tx] = src[(int64_t)ty * g.pitch + tx];
+    // Stage the cell with aligned 32-bit loads: rows start 32-byte aligned in the
+    // plane, so the cell's first column sits ox = iniX & 3 bytes into its first dword.
+    const int ox = iniX & 3;
+    const int ndw = (ox + cw + 3) >> 2;
+    const uint8_t *src = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)iniY * g.pitch + (iniX - ox);
+    {
+        const int c = tid & 31, r0 = tid >> 5;
+        if (c < ndw)
+            for (int r = r0; r < ch; r += 8)
+                reinterpret_cast<uint32_t *>(tile)[r * (kTP / 4) + c] = *reinterpret_cast<const uint32_t *>(src + (int64_t)r * g.pitch + 4 * c);
     }
-    for (int i = tid; i < (hi + 2) * kTP; i += 256) score[i] = 0;
+    for (int i = tid; i < (hi + 2) * (kTP / 4); i += 256) reinterpret_cast<uint32_t *>(score)[i] = 0;
+    const int npix = wi * hi;
+    for (int i = tid; i < ((npix + 15) >> 2); i += 256) reinterpret_cast<uint32_t *>(flag)[i] = 0;
     if (tid == 0) qn = 0;
     __syncthreads();
 
     // stage 1: cheap rejection at the lower threshold; survivors are compacted
     // into a queue so the expensive arc evaluation runs on dense waves.
     const int t = G.minTh;
-    for (int i = tid; i < wi * hi; i += 256) {
-        const int y = i / wi, x = i - y * wi;
-        const uint8_t *c = tile + (y + 3) * kTP + (x + 3);
+    const int mdiv = ((1 << 20) + wi - 1) / wi;
+    const uint8_t *t0 = tile + ox;  // pixel (x, y) of the cell image is t0[y * kTP + x]
+    for (int i = tid; i < npix; i += 256) {
+        const int y = div_small(i, mdiv), x = i - y * wi;
+        const uint8_t *c = t0 + (y + 3) * kTP + (x + 3);
         const int v = c[0], lo = v - t, hi_ = v + t;
         // any 9-long arc contains one pixel of each opposite pair (k, k+8)
-#define ORB_CLS(off) ((int)c[off] < lo ? 1 : ((int)c[off] > hi_ ? 2 : 0))
-        int dcls = ORB_CLS(3 * kTP) | ORB_CLS(-3 * kTP);
-        if (dcls) dcls &= ORB_CLS(3) | ORB_CLS(-3);
-        if (dcls) dcls &= (ORB_CLS(2 * kTP + 2) | ORB_CLS(-2 * kTP - 2));
-        if (dcls) dcls &= (ORB_CLS(-2 * kTP + 2) | ORB_CLS(2 * kTP - 2));
-#undef ORB_CLS
-        if (dcls) {
-            const int pos = atomicAdd(&qn, 1);
-            queue[pos] = (uint16_t)i;
-        }
+        const int p0 = c[3 * kTP], p8 = c[-3 * kTP], p4 = c[3], p12 = c[-3];
+        const int p2 = c[2 * kTP + 2], p10 = c[-2 * kTP - 2], p6 = c[-2 * kTP + 2], p14 = c[2 * kTP - 2];
+        const bool dark = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo) && (p2 < lo || p10 < lo) && (p6 < lo || p14 < lo);
+        const bool bright = (p0 > hi_ || p8 > hi_) && (p4 > hi_ || p12 > hi_) && (p2 > hi_ || p10 > hi_) && (p6 > hi_ || p14 > hi_);
+        if (dark || bright) queue[atomicAdd(&qn, 1)] = (uint16_t)i;
     }
     __syncthreads();
     const int nq = qn;
     for (int q = tid; q < nq; q += 256) {
         const int i = queue[q];
-        const int y = i / wi, x = i - y * wi;
-        const int A = fast_arc_strength(tile + (y + 3) * kTP + (x + 3));
+        const int y = div_small(i, mdiv), x = i - y * wi;
+        const int A = fast_arc_strength(t0 + (y + 3) * kTP + (x + 3));
         if (A > t) score[(y + 1) * kTP + (x + 1)] = (uint8_t)(A - 1);
     }
     __syncthreads();
-
-    // stage 2: strict 3x3 maximum inside the cell, threshold choice, ordered
-    // (row-major) emission.  Each thread owns a contiguous run of pixels.
-    const int npix = wi * hi, per = (npix + 255) >> 8;
-    const int p0 = tid * per;
-    uint32_t mmax = 0, mini = 0;
-    for (int k = 0; k < per; k++) {
-        const int i = p0 + k;
-        if (i >= npix) break;
-        const int y = i / wi, x = i - y * wi;
+    // stage 2: strict 3x3 maximum inside the cell, evaluated for the corners only
+    for (int q = tid; q < nq; q += 256) {
+        const int i = queue[q];
+        const int y = div_small(i, mdiv), x = i - y * wi;
         const uint8_t *s = score + (y + 1) * kTP + (x + 1);
         const int sc = s[0];
         if (sc == 0) continue;
         const bool ismax = sc > s[-1] && sc > s[1] && sc > s[-kTP - 1] && sc > s[-kTP] && sc > s[-kTP + 1] &&
                            sc > s[kTP - 1] && sc > s[kTP] && sc > s[kTP + 1];
-        if (ismax) {
-            mmax |= 1u << k;
-            if (sc >= G.iniTh) mini |= 1u << k;
+        if (ismax) flag[i] = (uint8_t)(1 | (sc >= G.iniTh ? 2 : 0));
+    }
+    __syncthreads();
+
+    // stage 3: threshold choice and ordered (row-major) emission; a thread owns
+    // a run of `per` consecutive pixels (a multiple of 4: whole flag dwords)
+    const int per = ((npix + 1023) >> 10) << 2;
+    const int p0i = tid * per;
+    uint32_t mmax = 0, mini = 0;
+    if (p0i < npix) {
+        for (int w = 0; w < (per >> 2); w++) {
+            const uint32_t fw = reinterpret_cast<const uint32_t *>(flag)[(p0i >> 2) + w];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t b = (fw >> (8 * k)) & 3u;
+                mmax |= (b & 1u) << (4 * w + k);
+                mini |= (b >> 1) << (4 * w + k);
+            }
         }
     }
     int total;
     const int packed = __popc(mini) | (__popc(mmax) << 16);
     const int excl = block_scan_excl(packed, &total, scan_lds);
     const bool use_ini = (total & 0xFFFF) > 0;
-    const uint32_t m = use_ini ? mini : mmax;
+    uint32_t m = use_ini ? mini : mmax;
     int pos = use_ini ? (excl & 0xFFFF) : (excl >> 16);
     const int count = use_ini ? (total & 0xFFFF) : (total >> 16);
     uint32_t *slot = slots + (int64_t)f * G.slot_frame_u32 + g.slot_off + (int64_t)ci * g.cell_cap;
-    for (int k = 0; k < per; k++) {
-        if (!(m >> k & 1u)) continue;
-        const int i = p0 + k;
-        const int y = i / wi, x = i - y * wi;
+    while (m) {
+        const int k = __ffs((int)m) - 1;
+        m &= m - 1;
+        const int i = p0i + k;
+        const int y = div_small(i, mdiv), x = i - y * wi;
         const int sc = score[(y + 1) * kTP + (x + 1)];
         // keypoint coordinates relative to (16,16): sub-image x (+3 apron) + j*wCell (:1099-1100)
         if (pos < g.cell_cap) slot[pos] = pack_cand(x + 3 + ci_j * g.wCell, y + 3 + ci_i * g.hCell, sc);
