@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--cpu-frames", type=int, default=150, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -145,6 +145,25 @@ def main():
     kp_mean = float(d_cnt[1:].float().mean().item())
     nm_mean = float(d_nm.float().mean().item())
 
+    latency = None
+    if rank == 0:
+        # single-frame latency through the host-pointer API (H2D image, D2H features, sync): not part of `value`
+        ex1 = api.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H)
+        mt1 = api.ORBmatcher(0.9, True, device=local_rank)
+        k0, d0 = ex1(frames[0]); k1, d1 = ex1(frames[1])
+        q1 = api.shift_queries(k0, -STEP[0], -STEP[1], TH_PROJ, scale, bounds)
+        for _ in range(5):
+            ex1(frames[1]); mt1.SearchByProjection(api.MODE_LAST_FRAME, q1, d0, k1, d1, bounds)
+        t1 = time.perf_counter()
+        for _ in range(50):
+            ex1(frames[1])
+        t2 = time.perf_counter()
+        for _ in range(50):
+            mt1.SearchByProjection(api.MODE_LAST_FRAME, q1, d0, k1, d1, bounds)
+        t3 = time.perf_counter()
+        latency = {"extract_ms": (t2 - t1) / 50 * 1e3, "match_ms": (t3 - t2) / 50 * 1e3,
+                   "note": "one frame through the host-pointer C ABI incl. PCIe both ways and the Python call"}
+
     if rank == 0:
         P, sizes = level_pixels(W, H)
         # algorithmic HBM bytes per frame of each extractor stage
@@ -188,6 +207,7 @@ def main():
             "extract_algorithmic_GBps": frame_alg * B / (float(stage_ms.sum()) * 1e-3) / 1e9,
             "gpu_ms_per_step": gpu_ms / args.steps,
             "window_resolver_iterations_rescans": wstats,
+            "single_frame_latency": latency,
         }
         if args.cpu_frames > 0 and world == 1:
             fps, dt = cpu_baseline(frames, args.cpu_frames)

@@ -245,7 +245,8 @@ static int ensure_buffers(orbgpu_extractor *e, const Geom &G, int batch, int img
     ENS(st_desc, B * (size_t)G.total_kp_cap * 32);
     ENS(st_counts, B * 4);
 #undef ENS
-    const size_t pin = B * (size_t)G.total_kp_cap * (sizeof(orbgpu_keypoint) + 32) + B * 4 + 64;
+    // pinned staging: outputs (keypoints, descriptors, counts, status) followed by the input images
+    const size_t pin = B * (size_t)G.total_kp_cap * (sizeof(orbgpu_keypoint) + 32) + B * 4 + 64 + B * (size_t)img_w * img_h;
     if (pin > e->h_pinned_bytes) {
         if (e->h_pinned) (void)hipHostFree(e->h_pinned);
         e->h_pinned = nullptr;
@@ -501,11 +502,15 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
     if (rc) return rc;
     hipStream_t st = e->stream;
     const int cap = e->G.total_kp_cap;
+    uint8_t *h_in = (uint8_t *)e->h_pinned + (size_t)e->p.max_batch * cap * (sizeof(orbgpu_keypoint) + 32) + (size_t)e->p.max_batch * 4 + 64;
+    // the previous call's device-to-host copies have completed (every host entry point synchronises)
     for (int f = 0; f < nimg; f++) {
         if (!imgs[f]) { set_error("image %d is NULL", f); return ORBGPU_E_INVALID; }
-        ORBGPU_HIP_CHECK(hipMemcpy2DAsync((uint8_t *)e->st_img.p + (size_t)f * w * h, w, imgs[f], stride, w, h,
-                                          hipMemcpyHostToDevice, st));
+        // pageable -> pinned on the host (a 2-D copy from pageable memory stalls for milliseconds)
+        uint8_t *hin = h_in + (size_t)f * w * h;
+        for (int y = 0; y < h; y++) memcpy(hin + (size_t)y * w, imgs[f] + (size_t)y * stride, (size_t)w);
     }
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(e->st_img.p, h_in, (size_t)nimg * w * h, hipMemcpyHostToDevice, st));
     rc = orbgpu_extract_batch_device(e, (const uint8_t *)e->st_img.p, nimg, w, h, w, (size_t)w * h,
                                      (orbgpu_keypoint *)e->st_kps.p, (uint8_t *)e->st_desc.p, cap, (int32_t *)e->st_counts.p);
     if (rc) return rc;

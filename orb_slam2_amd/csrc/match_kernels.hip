@@ -15,6 +15,21 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+// popcount(x) + acc in one instruction (v_bcnt_u32_b32 accumulates)
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t hamming8_chain(const uint32_t (&a)[8], const uint32_t *__restrict__ b)
+{
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d = bcnt_acc(a[k] ^ b[k], d);
+    return d;
+}
+
 // ---------------------------------------------------------------------------
 // Brute force: every query against every train descriptor.  A thread owns one
 // query (8 VGPRs); the train descriptor index is wave-uniform so its 8 words
@@ -40,14 +55,14 @@ __global__ __launch_bounds__(256) void k_bf_partial(const uint32_t *__restrict__
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t *tp = T + (size_t)(j + u) * 8;
-            const uint32_t key = ((uint32_t)hamming8(a, tp) << 20) | (uint32_t)(j + u - t0);
+            const uint32_t key = (hamming8_chain(a, tp) << 20) | (uint32_t)(j + u - t0);
             k2 = med3_u32(k1, k2, key);  // second smallest of {k1<=k2, key}
             k1 = min(k1, key);
         }
     }
     for (; j < t1; j++) {
         const uint32_t *tp = T + (size_t)j * 8;
-        const uint32_t key = ((uint32_t)hamming8(a, tp) << 20) | (uint32_t)(j - t0);
+        const uint32_t key = (hamming8_chain(a, tp) << 20) | (uint32_t)(j - t0);
         k2 = med3_u32(k1, k2, key);
         k1 = min(k1, key);
     }

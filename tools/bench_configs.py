@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Side measurements for the other BASELINE.json configs (not the bench.py contract line):
+KITTI / EuRoC stereo frames through the host API, 4K batches device-resident, and the
+100k x 100k brute-force Hamming scan.  Prints one JSON object per config."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from orb_slam2_amd import api, synth  # noqa: E402
+
+dev = torch.device("cuda", 0)
+
+
+def timed(fn, n, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def stereo(name, w, h, nfeat, bf, fx, seed):
+    L, R, _ = synth.stereo_pair(w, h, seed=seed)
+    exL = api.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    exR = api.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    m = api.ORBmatcher()
+    res = {}
+
+    def frame():
+        kL, dL = exL(L); kR, dR = exR(R)
+        res["n"] = m.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, bf, bf / fx)[0]
+        res["kp"] = (len(kL), len(kR))
+    dt = timed(frame, 20)
+    print(json.dumps({"config": name, "ms_per_stereo_frame_host_api_incl_pcie": dt * 1e3, "keypoints": res["kp"],
+                      "stereo_matches": res["n"]}), flush=True)
+
+
+def batch_4k(B=16):
+    w, h = 3840, 2160
+    one = synth.sequence(w, h, 2, seed=4, n_shapes=3000)
+    d = torch.from_numpy(np.ascontiguousarray(np.repeat(one, B // 2, axis=0))).to(dev)
+    ex = api.ORBextractor(8000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    cap = ex.max_keypoints
+    k = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev); ds = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    c = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def step():
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, k.data_ptr(), ds.data_ptr(), cap, c.data_ptr())
+        ex.sync()
+    dt = timed(step, 5)
+    ex.profile(True); step(); ms, _ = ex.stage_times()
+    alg = 103190808
+    print(json.dumps({"config": "4K 3840x2160, 8000 features, batch %d device-resident" % B, "frames_per_s": B / dt,
+                      "algorithmic_GBps": alg * B / dt / 1e9, "keypoints_per_frame": float(c.float().mean().item()),
+                      "stages_ms": [float(x) for x in ms]}), flush=True)
+
+
+def brute(n=100000):
+    Q = torch.from_numpy(synth.descriptors(n, 5)).to(dev); T = torch.from_numpy(synth.descriptors(n, 6)).to(dev)
+    m = api.ORBmatcher()
+    bi = torch.zeros(n, dtype=torch.int32, device=dev); b1 = torch.zeros_like(bi); b2 = torch.zeros_like(bi)
+
+    def step():
+        m.bruteforce_device(Q.data_ptr(), n, T.data_ptr(), n, bi.data_ptr(), b1.data_ptr(), b2.data_ptr())
+        m.sync()
+    dt = timed(step, 5)
+    pairs = float(n) * n
+    lanes_clk = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock
+    print(json.dumps({"config": "brute force %dk x %dk x 256 bit" % (n // 1000, n // 1000), "ms": dt * 1e3,
+                      "pairs_per_s": pairs / dt, "valu_util_at_16_ops_per_pair": 16 * pairs / dt / lanes_clk,
+                      "hbm_GBps": (64.0 * n + 12.0 * n) / dt / 1e9}), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["kitti", "euroc", "4k", "bf"]
+    if "kitti" in which:
+        stereo("KITTI 1241x376 stereo, 2000 features/side + ComputeStereoMatches", 1241, 376, 2000, 386.1448, 718.856, 2)
+    if "euroc" in which:
+        stereo("EuRoC 752x480 stereo, 1200 features/side + ComputeStereoMatches", 752, 480, 1200, 47.90639384423901, 435.2046959714599, 3)
+    if "4k" in which:
+        batch_4k()
+    if "bf" in which:
+        brute()
