@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--cpu-frames", type=int, default=150, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch

@@ -137,3 +137,22 @@ def test_unsupported_sizes_report_errors():
     ex = _mk(640, 480, 1000)
     with pytest.raises(OrbGpuError):
         ex(np.zeros((600, 800), np.uint8))  # larger than the handle was sized for
+
+
+def test_4k_frame_8000_features(oracle):
+    """BASELINE config 4 geometry (3840x2160, 8000 features): one frame, bit-exact against the oracle."""
+    img = synth.sequence(3840, 2160, 1, seed=4, n_shapes=3000)[0]
+    ex = _mk(3840, 2160, 8000)
+    oe = oracle.Extractor(8000)
+    kps, desc = ex(img)
+    okps, odesc = oe.extract(img)
+    assert len(kps) == len(okps) and len(kps) > 4000
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(kps[f], okps[f]), f
+    dang = np.abs(kps["angle"] - okps["angle"])
+    assert np.minimum(dang, 360 - dang).max() <= np.degrees(1e-4)
+    assert int((desc != odesc).any(axis=1).sum()) <= 0.001 * len(desc)
+    # size-independent properties at full size: level 0 is the input, every level carries its reflect-101 halo
+    assert np.array_equal(ex.pyramid_level(0), img)
+    top = ex.pyramid_level(7, border=19)
+    assert np.array_equal(top, np.pad(top[19:-19, 19:-19], 19, mode="reflect"))

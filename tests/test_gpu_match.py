@@ -155,3 +155,43 @@ def test_stereo_matches(oracle):
     assert n == rn
     assert np.array_equal(uR, ruR) and np.array_equal(dep, rdep)
     assert n > 100
+
+
+def test_stereo_matches_kitti_geometry(oracle):
+    """BASELINE config 2 geometry: 1241x376, 2000 features per side, KITTI bf / baseline."""
+    from orb_slam2_amd.api import ORBextractor, ORBmatcher
+    L, R, disp = synth.stereo_pair(1241, 376, seed=2)
+    exL = ORBextractor(2000, 1.2, 8, 20, 7, max_width=1241, max_height=376)
+    exR = ORBextractor(2000, 1.2, 8, 20, 7, max_width=1241, max_height=376)
+    kL, dL = exL(L)
+    kR, dR = exR(R)
+    bf, fx = 386.1448, 718.856
+    m = ORBmatcher()
+    n, uR, dep = m.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, bf, bf / fx)
+    t = oracle.tables(oracle.make_params(2000))
+    pyrL = [exL.pyramid_level(l) for l in range(8)]
+    pyrR = [exR.pyramid_level(l) for l in range(8)]
+    rn, ruR, rdep = oracle.stereo_matches(kL.view(oracle.KEYPOINT_DTYPE), dL, kR.view(oracle.KEYPOINT_DTYPE), dR, pyrL,
+                                          pyrR, t["scale"], t["inv_scale"], bf, bf / fx)
+    assert n == rn and n > 200
+    assert np.array_equal(uR, ruR) and np.array_equal(dep, rdep)
+    ok = uR >= 0
+    d_true = disp[np.clip(kL["y"][ok].astype(int), 0, 375)]
+    assert np.mean(np.abs((kL["x"][ok] - uR[ok]) - d_true) < 1.5) > 0.8
+
+
+def test_bruteforce_100k_properties(matcher):
+    """BASELINE config 5 size: 100k x 100k.  Checked through size-independent properties
+    (planted partner recovery, self-match, distance symmetry on a sample)."""
+    from orb_slam2_amd.api import ORBmatcher
+    Q = synth.descriptors(100000, 5)
+    T, perm = synth.planted(Q, 6)
+    bi, b1, b2 = matcher.BruteForce(Q, T)
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    assert (bi == inv).mean() > 0.999
+    assert (b1 <= b2).all() and b1.max() <= 256
+    sub = np.arange(0, 100000, 1013)
+    for i in sub[:40]:
+        assert b1[i] == ORBmatcher.DescriptorDistance(Q[i], T[bi[i]])
+    si, s1, s2 = matcher.BruteForce(Q[:5000], Q[:5000])
+    assert np.array_equal(si, np.arange(5000)) and (s1 == 0).all() and (s2 > 0).all()
