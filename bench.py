@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency probe (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -146,7 +147,7 @@ def main():
     nm_mean = float(d_nm.float().mean().item())
 
     latency = None
-    if rank == 0:
+    if rank == 0 and not args.no_latency:
         # single-frame latency through the host-pointer API (H2D image, D2H features, sync): not part of `value`
         ex1 = api.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H)
         mt1 = api.ORBmatcher(0.9, True, device=local_rank)
@@ -182,6 +183,16 @@ def main():
         # the quadtree moves O(N) bytes; price it (if dominant) by the candidate bytes it gathers
         dom_bytes = alg[dom_name] * B if alg[dom_name] else 4 * 4000 * B
         achieved = dom_bytes / (float(stage_ms[dom]) * 1e-3) / 1e9
+        # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (same batch size only)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pm.get("batch") == B:
+                kk = pm["kernels"][{"pyramid": "k_pyr_resize", "fast_cells": "k_fast_cells", "octree": "k_octree", "blur": "k_blur",
+                                    "describe": "k_describe"}[dom_name]]
+                traffic = (kk["FETCH_SIZE_KB_per_launch"] * kk.get("fetch_corr", 1.0) + kk["WRITE_SIZE_KB_per_launch"]) * 1024
+        except Exception:
+            traffic = None
         frame_alg = W * H + (P - W * H) + P + 2 * P + int(kp_mean * 60)
         out = {
             "metric": "frames/sec ORB extract+match at 640x480/1000 kp",
@@ -201,7 +212,7 @@ def main():
                        "batch_per_gpu": B, "keypoints_per_frame": kp_mean, "matches_per_frame": nm_mean,
                        "parallelism": "frames sharded across %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": float(stage_ms[dom])},
             "stages_ms_per_step": dict({n: float(v) for n, v in zip(names, stage_ms)}, match=match_ms),
             "extract_algorithmic_GBps": frame_alg * B / (float(stage_ms.sum()) * 1e-3) / 1e9,

@@ -261,27 +261,43 @@ __device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P
         if (DYN) {
             top2_push(t2, key);
         } else {
-            // extract this chunk's candidates in ascending order on a 32-bit key
-            // (distance << 22 | window ordinal; ordinals are unique) and insert
-            // them into the sorted cache
-            npass += __popcll(__ballot(key != kNoKey));
-            uint32_t k32 = key == kNoKey ? 0xFFFFFFFFu : ((uint32_t)(key >> 40) << 22) | (uint32_t)((key >> 20) & 0xFFFFFu);
-            for (int rnd = 0; rnd < kTopK; rnd++) {
-                uint32_t m = k32;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
-                if (m == 0xFFFFFFFFu) break;
-                const int src = __ffsll((long long)__ballot(k32 == m)) - 1;
-                const unsigned long long mk = shfl_u64(key, src);
-                if (nk == kTopK && mk >= wk[kTopK - 1]) break;
-                if (lane == 0) {
-                    int p = nk < kTopK ? nk : kTopK - 1;  // keys of one chunk arrive in ascending order: usually a plain append
-                    while (p > 0 && wk[p - 1] > mk) { wk[p] = wk[p - 1]; p--; }
-                    wk[p] = mk;
-                }
-                if (nk < kTopK) nk++;
+            // The cache is an unordered set (the resolver takes minima): while it has
+            // room the chunk's candidates are appended by ballot rank; once it would
+            // overflow, candidates are taken in ascending order and evict the
+            // largest cached key, so the cache ends as the kTopK smallest keys.
+            const unsigned long long vb = __ballot(key != kNoKey);
+            const int nv = __popcll(vb);
+            npass += nv;
+            if (nk + nv <= kTopK) {
+                if (key != kNoKey) wk[nk + __popcll(vb & ((1ull << lane) - 1ull))] = key;
+                nk += nv;
                 __builtin_amdgcn_wave_barrier();
-                if (lane == src) k32 = 0xFFFFFFFFu;
+            } else {
+                uint32_t k32 = key == kNoKey ? 0xFFFFFFFFu : ((uint32_t)(key >> 40) << 22) | (uint32_t)((key >> 20) & 0xFFFFFu);
+                for (int rnd = 0; rnd < 64; rnd++) {
+                    uint32_t m = k32;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+                    if (m == 0xFFFFFFFFu) break;
+                    const int src = __ffsll((long long)__ballot(k32 == m)) - 1;
+                    const unsigned long long mk = shfl_u64(key, src);
+                    if (lane == src) k32 = 0xFFFFFFFFu;
+                    if (nk < kTopK) {
+                        if (lane == 0) wk[nk] = mk;
+                        nk++;
+                        __builtin_amdgcn_wave_barrier();
+                        continue;
+                    }
+                    // largest cached key and its slot
+                    unsigned long long mx = lane < kTopK ? wk[lane] : 0ull;
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) mx = max(mx, shfl_xor_u64(mx, o));
+                    mx = shfl_u64(mx, 0);
+                    if (mk >= mx) break;  // later candidates of this chunk are larger still
+                    const int slot = __ffsll((long long)__ballot(lane < kTopK && wk[lane] == mx)) - 1;
+                    if (lane == 0) wk[slot] = mk;
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
     }
@@ -380,24 +396,25 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
         }
         ncand0 = P.ncand[tid];
     }
+    const int qflags0 = tid < nq ? P.Q[tid].flags : 0;
     __syncthreads();
 
     // one query against the current claims: first one or two surviving cached candidates
     auto evaluate = [&](int i, const unsigned long long (&key)[kTopK], int ncand) {
-        bool gone[kTopK];
-#pragma unroll
-        for (int k = 0; k < kTopK; k++)
-            gone[k] = key[k] != kNoKey && claimed_by_earlier(P, mode, 0, i, key_train(key[k]), key_dist(key[k]));
+        // the two smallest cached keys that no earlier query has claimed
         unsigned long long b1 = kNoKey, b2 = kNoKey;
-        bool exhausted = true;  // all kTopK entries valid and still undecided
+        int nvalid = 0;
 #pragma unroll
         for (int k = 0; k < kTopK; k++) {
-            if (!exhausted) continue;
-            if (key[k] == kNoKey) { exhausted = false; continue; }
-            if (gone[k]) continue;
-            if (b1 == kNoKey) { b1 = key[k]; if (!need2) exhausted = false; }
-            else { b2 = key[k]; exhausted = false; }
+            const unsigned long long kk = key[k];
+            if (kk == kNoKey) continue;
+            nvalid++;
+            if (claimed_by_earlier(P, mode, 0, i, key_train(kk), key_dist(kk))) continue;
+            if (kk < b1) { b2 = b1; b1 = kk; }
+            else if (kk < b2) b2 = kk;
         }
+        // a full cache that cannot supply what the decision needs says nothing about the rest of the window
+        const bool exhausted = nvalid == kTopK && (b1 == kNoKey || (need2 && b2 == kNoKey));
         if (exhausted && ncand > kTopK) {
             P.full[i] = 1;  // the cache cannot decide: rescan the whole window below
         } else {
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
             const int s = selc[i];
             if (s < 0) continue;
             if (mode == 3) P.nxt[i] = atomicExch(&P.head[s], i);
-            else if (mode == 2 || (P.Q[i].flags & 2)) atomicMin(&P.head[s], i);
+            else if (mode == 2 || ((i == tid ? qflags0 : P.Q[i].flags) & 2)) atomicMin(&P.head[s], i);
         }
         __syncthreads();
         if (tid < nq) evaluate(tid, key0, ncand0);
