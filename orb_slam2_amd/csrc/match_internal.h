@@ -7,9 +7,9 @@ namespace orbgpu {
 constexpr int kTopK = 16;  // cached best candidates per windowed query
 __host__ __device__ inline size_t match_scratch_ints(int q_cap, int t_cap)
 {
-    // topk keys [2*kTopK*q_cap] | cell_start [3080] | grid records [4*t_cap] | grid descriptors [8*t_cap] | head [t_cap] |
+    // cached candidates [kTopK*q_cap] | cell_start [3080] | grid records [4*t_cap] | grid descriptors [8*t_cap] | head [t_cap] |
     // ncand, sel x2, sd x2, nxt, full [q_cap each]; a multiple of 4 ints keeps every pair 16-byte aligned
-    return (3080 + 13 * (size_t)t_cap + (2 * kTopK + 7) * (size_t)q_cap + 3) & ~(size_t)3;
+    return (3080 + 13 * (size_t)t_cap + (kTopK + 7) * (size_t)q_cap + 3) & ~(size_t)3;
 }
 
 struct ScaleTab { float s[ORBGPU_MAX_LEVELS]; };

@@ -56,6 +56,14 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // key = distance << 40 | window ordinal << 20 | train index
 __device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 40); }
 __device__ __forceinline__ int key_train(unsigned long long k) { return (int)(k & 0xFFFFFull); }
+// cached candidates are stored in key order as distance << 20 | train index
+constexpr uint32_t kNoCand = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t cand_pack(unsigned long long k)
+{
+    return k == kNoKey ? kNoCand : ((uint32_t)key_dist(k) << 20) | (uint32_t)key_train(k);
+}
+__device__ __forceinline__ int cand_dist(uint32_t c) { return (int)(c >> 20); }
+__device__ __forceinline__ int cand_train(uint32_t c) { return (int)(c & 0xFFFFFu); }
 
 struct PairCtx {
     int nq, n2;
@@ -65,7 +73,7 @@ struct PairCtx {
     const float *UR;
     const uint8_t *OCC;
     int32_t *assign, *qmatch;
-    unsigned long long *topk;
+    uint32_t *topk;    // [query][kTopK] cached candidates, ascending key order, kNoCand padded
     int32_t *cell_start, *head, *ncand, *sel0, *sel1, *sd0, *sd1, *nxt, *full;
     const int32_t *sd_cur;  // distances of the current selections (SearchForInitialization claims)
     int4 *grec;        // grid-ordered train keypoints: {x bits, y bits, octave, index}
@@ -87,7 +95,7 @@ __device__ __forceinline__ PairCtx make_ctx(const MatchArgs &A, int pair)
     P.assign = A.assign + (size_t)pair * A.t_cap;
     P.qmatch = A.qmatch ? A.qmatch + (size_t)pair * A.q_cap : nullptr;
     int32_t *s = A.scratch + (size_t)pair * match_scratch_ints(A.q_cap, A.t_cap);
-    P.topk = (unsigned long long *)s;  s += 2 * kTopK * (size_t)A.q_cap;
+    P.topk = (uint32_t *)s;            s += kTopK * (size_t)A.q_cap;
     P.cell_start = s;                  s += 3080;
     P.grec = (int4 *)s;                s += 4 * (size_t)A.t_cap;
     P.gdesc = (uint32_t *)s;           s += 8 * (size_t)A.t_cap;
@@ -188,6 +196,18 @@ __device__ __forceinline__ bool claimed_by_earlier(const PairCtx &P, int mode, i
     return false;
 }
 
+// Can a candidate at this distance influence the decision of its query?  A
+// candidate beyond the acceptance threshold is never selected, and as the
+// runner-up it only matters while it can still fail the ratio test of decide():
+// dropping the others here leaves every decision unchanged and keeps the
+// per-query caches short.
+__device__ __forceinline__ bool cand_useful(const MatchArgs &A, int dist)
+{
+    if (A.mode == 3) return dist <= ORBGPU_TH_LOW || !((float)ORBGPU_TH_LOW < __fmul_rn((float)dist, A.nnratio));
+    if (dist <= A.th_dist) return true;
+    return A.mode == 0 && (float)A.th_dist > __fmul_rn(A.nnratio, (float)dist);
+}
+
 // DYN = false: cache the kTopK best candidates of the window in wk (LDS, sorted)
 // and count the candidates; DYN = true: apply the claims and return the two best.
 template <bool DYN>
@@ -254,7 +274,7 @@ __device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P
             if (ok) {
                 const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
                                  __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
-                if (!DYN || !claimed_by_earlier(P, mode, cur, i, t, dist))
+                if (cand_useful(A, dist) && (!DYN || !claimed_by_earlier(P, mode, cur, i, t, dist)))
                     key = ((unsigned long long)dist << 40) | ((unsigned long long)j << 20) | (unsigned)t;
             }
         }
@@ -317,6 +337,7 @@ __global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
 {
     __shared__ int wl[4][65], ws[4][64];
     __shared__ unsigned long long wk[4][kTopK];
+    __shared__ uint32_t wp[4][kTopK];
     const int pair = blockIdx.y, w = threadIdx.x >> 6, lane = lane_id();
     const int i = blockIdx.x * 4 + w;
     const PairCtx P = make_ctx(A, pair);
@@ -328,26 +349,34 @@ __global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
     int npass = 0;
     if (q.flags & 1) scan_window<false>(A, P, 0, i, q, wl[w], ws[w], wk[w], t2, npass);
     __builtin_amdgcn_wave_barrier();
-    if (lane < kTopK) P.topk[(size_t)i * kTopK + lane] = wk[w][lane];
+    // the cache is a set of distinct keys: rank = position in ascending key order
+    const unsigned long long my = lane < kTopK ? wk[w][lane] : kNoKey;
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < kTopK; k++) rank += wk[w][k] < my;
+    if (lane < kTopK) wp[w][lane] = kNoCand;
+    __builtin_amdgcn_wave_barrier();
+    if (my != kNoKey) wp[w][rank] = cand_pack(my);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < kTopK) P.topk[(size_t)i * kTopK + lane] = wp[w][lane];
     if (lane == 0) P.ncand[i] = npass;
 }
 
 // Acceptance rules of the four matchers, given the best two available candidates.
-__device__ __forceinline__ void decide(const MatchArgs &A, const PairCtx &P, unsigned long long b1, unsigned long long b2,
-                                       int &newsel, int &newd)
+__device__ __forceinline__ void decide(const MatchArgs &A, const PairCtx &P, uint32_t b1, uint32_t b2, int &newsel, int &newd)
 {
     newsel = -1;
     newd = 0;
-    if (b1 == kNoKey) return;
-    const int best = key_dist(b1), bidx = key_train(b1);
+    if (b1 == kNoCand) return;
+    const int best = cand_dist(b1), bidx = cand_train(b1);
     bool ok;
     if (A.mode == 3) {  // src/ORBmatcher.cc:496-499
-        const float best2 = b2 != kNoKey ? (float)key_dist(b2) : 2147483648.0f;
+        const float best2 = b2 != kNoCand ? (float)cand_dist(b2) : 2147483648.0f;
         ok = best <= ORBGPU_TH_LOW && (float)best < __fmul_rn(best2, A.nnratio);
     } else {
         ok = best <= A.th_dist;
-        if (ok && A.mode == 0 && b2 != kNoKey) {  // ratio test only within one pyramid level (src/ORBmatcher.cc:118-121)
-            const int best2 = key_dist(b2), bidx2 = key_train(b2);
+        if (ok && A.mode == 0 && b2 != kNoCand) {  // ratio test only within one pyramid level (src/ORBmatcher.cc:118-121)
+            const int best2 = cand_dist(b2), bidx2 = cand_train(b2);
             if (P.K2[bidx].octave == P.K2[bidx2].octave && (float)best > __fmul_rn(A.nnratio, (float)best2)) ok = false;
         }
     }
@@ -362,7 +391,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
     extern __shared__ __align__(16) int dyn_state[];
     __shared__ int wl[16][65], ws[16][64];
     __shared__ int hist[ORBGPU_HISTO_LENGTH];
-    __shared__ int sh_changed, sh_keep[3];
+    __shared__ int sh_changed, sh_nrescan, sh_keep[3];
 
     const int pair = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x;
     const int lane = lane_id(), wid = tid >> 6, nw = nt_ >> 6;
@@ -384,41 +413,46 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
     int32_t *selc = P.sel0, *seln = P.sel1, *sdc = P.sd0, *sdn = P.sd1;  // current / next state
     for (int i = tid; i < nq; i += nt_) { selc[i] = -1; sdc[i] = 0; }
     // the cached candidates never change: keep those of the thread's first query in registers
-    unsigned long long key0[kTopK];
+    uint32_t key0[kTopK];
+#pragma unroll
+    for (int k = 0; k < kTopK; k++) key0[k] = kNoCand;
     int ncand0 = 0;
     if (tid < nq) {
-        const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(P.topk + (size_t)tid * kTopK);
+        const uint4 *kp = reinterpret_cast<const uint4 *>(P.topk + (size_t)tid * kTopK);
 #pragma unroll
-        for (int k = 0; k < kTopK / 2; k++) {
-            const ulonglong2 v = kp[k];
-            key0[2 * k] = v.x;
-            key0[2 * k + 1] = v.y;
+        for (int k = 0; k < kTopK / 4; k++) {
+            const uint4 v = kp[k];
+            key0[4 * k] = v.x; key0[4 * k + 1] = v.y; key0[4 * k + 2] = v.z; key0[4 * k + 3] = v.w;
         }
         ncand0 = P.ncand[tid];
     }
     const int qflags0 = tid < nq ? P.Q[tid].flags : 0;
     __syncthreads();
 
-    // one query against the current claims: first one or two surviving cached candidates
-    auto evaluate = [&](int i, const unsigned long long (&key)[kTopK], int ncand) {
-        // the two smallest cached keys that no earlier query has claimed
-        unsigned long long b1 = kNoKey, b2 = kNoKey;
-        int nvalid = 0;
+    // one query against the current claims: the first one or two cached candidates
+    // (in key order) that no earlier query has claimed
+    auto evaluate = [&](int i, const uint32_t (&key)[kTopK], int ncand) {
+        uint32_t b1 = kNoCand, b2 = kNoCand;
+        if (mode != 3) {
+            int h[kTopK];  // claim words of all cached candidates: independent loads
 #pragma unroll
-        for (int k = 0; k < kTopK; k++) {
-            const unsigned long long kk = key[k];
-            if (kk == kNoKey) continue;
-            nvalid++;
-            if (claimed_by_earlier(P, mode, 0, i, key_train(kk), key_dist(kk))) continue;
-            if (kk < b1) { b2 = b1; b1 = kk; }
-            else if (kk < b2) b2 = kk;
-        }
-        // a full cache that cannot supply what the decision needs says nothing about the rest of the window
-        const bool exhausted = nvalid == kTopK && (b1 == kNoKey || (need2 && b2 == kNoKey));
-        if (exhausted && ncand > kTopK) {
-            P.full[i] = 1;  // the cache cannot decide: rescan the whole window below
+            for (int k = 0; k < kTopK; k++) h[k] = P.head[key[k] == kNoCand ? 0 : cand_train(key[k])];
+#pragma unroll
+            for (int k = kTopK - 1; k >= 0; k--)
+                if (key[k] != kNoCand && h[k] >= i) { b2 = b1; b1 = key[k]; }
         } else {
-            P.full[i] = 0;
+#pragma unroll
+            for (int k = 0; k < kTopK; k++) {
+                const uint32_t kk = key[k];
+                if (kk == kNoCand || b2 != kNoCand) continue;
+                if (claimed_by_earlier(P, mode, 0, i, cand_train(kk), cand_dist(kk))) continue;
+                if (b1 == kNoCand) b1 = kk; else b2 = kk;
+            }
+        }
+        // a truncated cache that cannot supply what the decision needs says nothing about the rest of the window
+        if (ncand > kTopK && (b1 == kNoCand || (need2 && b2 == kNoCand))) {
+            P.full[atomicAdd(&sh_nrescan, 1)] = i;  // rescan the whole window below
+        } else {
             int ns, nd;
             decide(A, P, b1, b2, ns, nd);
             if (ns != selc[i] || nd != sdc[i]) sh_changed = 1;
@@ -432,7 +466,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
     for (int it = 0; it <= nq + 1; it++) {
         n_iter++;
         for (int i = tid; i < n2; i += nt_) P.head[i] = (mode == 3) ? -1 : 0x7FFFFFFF;
-        if (tid == 0) sh_changed = 0;
+        if (tid == 0) { sh_changed = 0; sh_nrescan = 0; }
         __syncthreads();
         for (int i = tid; i < nq; i += nt_) {
             const int s = selc[i];
@@ -443,36 +477,30 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
         __syncthreads();
         if (tid < nq) evaluate(tid, key0, ncand0);
         for (int i = tid + nt_; i < nq; i += nt_) {
-            unsigned long long key[kTopK];
-            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(P.topk + (size_t)i * kTopK);
+            uint32_t key[kTopK];
+            const uint4 *kp = reinterpret_cast<const uint4 *>(P.topk + (size_t)i * kTopK);
 #pragma unroll
-            for (int k = 0; k < kTopK / 2; k++) {
-                const ulonglong2 v = kp[k];
-                key[2 * k] = v.x;
-                key[2 * k + 1] = v.y;
+            for (int k = 0; k < kTopK / 4; k++) {
+                const uint4 v = kp[k];
+                key[4 * k] = v.x; key[4 * k + 1] = v.y; key[4 * k + 2] = v.z; key[4 * k + 3] = v.w;
             }
             evaluate(i, key, P.ncand[i]);
         }
         __syncthreads();
-        // queries the cache could not decide: each wave takes 64 queries, finds the
-        // flagged ones with one load + ballot, and rescans their windows
-        for (int base = wid * 64; base < nq; base += nw * 64) {
-            const int fi = base + lane;
-            unsigned long long m = __ballot(fi < nq && P.full[fi] != 0);
-            while (m) {
-                const int i = base + __ffsll((long long)m) - 1;
-                m &= m - 1;
-                n_full++;
-                Top2 t2;
-                int npass;
-                scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
-                if (lane == 0) {
-                    int ns, nd;
-                    decide(A, P, t2.a, t2.b, ns, nd);
-                    if (ns != selc[i] || nd != sdc[i]) sh_changed = 1;
-                    seln[i] = ns;
-                    sdn[i] = nd;
-                }
+        // queries the cache could not decide: one wave per listed query rescans its window
+        const int nrescan = sh_nrescan;
+        for (int r = wid; r < nrescan; r += nw) {
+            const int i = P.full[r];
+            n_full++;
+            Top2 t2;
+            int npass;
+            scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
+            if (lane == 0) {
+                int ns, nd;
+                decide(A, P, cand_pack(t2.a), cand_pack(t2.b), ns, nd);
+                if (ns != selc[i] || nd != sdc[i]) sh_changed = 1;
+                seln[i] = ns;
+                sdn[i] = nd;
             }
         }
         __syncthreads();
