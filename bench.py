@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--streams", type=int, default=1, help="independent sub-pipelines (HIP streams) the batch is split over")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency probe (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -87,11 +88,22 @@ def main():
     frames = synth.sequence(W, H, B, seed=1 + rank, step=STEP)
     d_imgs = torch.from_numpy(frames).to(dev)
 
-    ex = api.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H, max_batch=B)
-    mt = api.ORBmatcher(0.9, True, device=local_rank)
-    stream = torch.cuda.Stream(device=dev)
-    ex.set_stream(stream.cuda_stream)
-    mt.set_stream(stream.cuda_stream)
+    # S independent sub-pipelines (own extractor + matcher handle, own HIP stream), each taking B/S
+    # consecutive frames of the batch: the latency-bound kernels of one overlap the ALU-bound ones of another
+    S = args.streams
+    assert B % S == 0, "--batch must be a multiple of --streams"
+    Bs = B // S
+    exs = [api.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H, max_batch=Bs)
+           for _ in range(S)]
+    mts = [api.ORBmatcher(0.9, True, device=local_rank) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    for e, m, st in zip(exs, mts, streams):
+        e.set_stream(st.cuda_stream)
+        m.set_stream(st.cuda_stream)
+    ex, mt, stream = exs[0], mts[0], streams[0]
+    ev_extracted = [torch.cuda.Event() for _ in range(S)]
+    ev_matched = [torch.cuda.Event() for _ in range(S)]
+    ev_carried = torch.cuda.Event()
     cap = ex.max_keypoints
     scale = ex.GetScaleFactors()
     bounds = np.array([0, 0, W, H], np.float32)
@@ -105,18 +117,31 @@ def main():
     d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
 
     def step():
-        with torch.cuda.stream(stream):
-            ex.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, W * H, d_kps[1].data_ptr(), d_desc[1].data_ptr(), cap,
-                                    d_cnt[1:].data_ptr())
-            mt.make_shift_queries_device(B, d_kps.data_ptr(), d_cnt.data_ptr(), cap, -float(STEP[0]), -float(STEP[1]),
-                                         TH_PROJ, scale, bounds, d_q.data_ptr())
-            mt.search_by_projection_batch_device(api.MODE_LAST_FRAME, B, d_q.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(),
-                                                 cap, d_kps[1].data_ptr(), d_desc[1].data_ptr(), d_cnt[1:].data_ptr(), cap,
-                                                 bounds, d_assign.data_ptr(), d_nm.data_ptr(), th_dist=api.TH_HIGH)
-            # carry the last frame into slot 0 for the next step
+        for k in range(S):
+            lo = k * Bs  # frames lo .. lo+Bs-1 of the batch live in slots lo+1 .. lo+Bs
+            with torch.cuda.stream(streams[k]):
+                # slot lo+1.. are still read by the previous step's matching on the next stream (its slot "lo+Bs")
+                streams[k].wait_event(ev_matched[k + 1] if k + 1 < S else ev_carried)
+                exs[k].extract_batch_device(d_imgs[lo].data_ptr(), Bs, W, H, W, W * H, d_kps[lo + 1].data_ptr(),
+                                            d_desc[lo + 1].data_ptr(), cap, d_cnt[lo + 1:].data_ptr())
+                ev_extracted[k].record(streams[k])
+                # the predecessor of this sub-batch's first frame comes from the previous sub-batch (slot lo)
+                if k > 0:
+                    streams[k].wait_event(ev_extracted[k - 1])
+                mts[k].make_shift_queries_device(Bs, d_kps[lo].data_ptr(), d_cnt[lo:].data_ptr(), cap, -float(STEP[0]),
+                                                 -float(STEP[1]), TH_PROJ, scale, bounds, d_q[lo].data_ptr())
+                mts[k].search_by_projection_batch_device(api.MODE_LAST_FRAME, Bs, d_q[lo].data_ptr(), d_desc[lo].data_ptr(),
+                                                         d_cnt[lo:].data_ptr(), cap, d_kps[lo + 1].data_ptr(),
+                                                         d_desc[lo + 1].data_ptr(), d_cnt[lo + 1:].data_ptr(), cap, bounds,
+                                                         d_assign[lo].data_ptr(), d_nm[lo:].data_ptr(), th_dist=api.TH_HIGH)
+                ev_matched[k].record(streams[k])
+        with torch.cuda.stream(streams[0]):
+            # carry the last frame into slot 0 for the next step (after sub-pipeline 0 has matched against the old slot 0)
+            streams[0].wait_event(ev_extracted[S - 1])
             d_kps[0].copy_(d_kps[B], non_blocking=True)
             d_desc[0].copy_(d_desc[B], non_blocking=True)
             d_cnt[0:1].copy_(d_cnt[B:B + 1], non_blocking=True)
+            ev_carried.record(streams[0])
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -133,6 +158,8 @@ def main():
     ev0.record(stream)
     for _ in range(args.steps):
         step()
+    for k in range(1, S):
+        stream.wait_event(ev_matched[k])
     ev1.record(stream)
     barrier()
     wall = time.perf_counter() - t0
@@ -142,7 +169,7 @@ def main():
 
     wall_max = max_over_ranks(wall, dev)
 
-    wstats = [mt.window_stats(p) for p in range(0, B, max(1, B // 8))]
+    wstats = [mt.window_stats(p) for p in range(0, Bs, max(1, Bs // 8))]
     kp_mean = float(d_cnt[1:].float().mean().item())
     nm_mean = float(d_nm.float().mean().item())
 
@@ -177,17 +204,17 @@ def main():
         }
         names = ["pyramid", "fast_cells", "octree", "blur", "describe"]
         # the blur runs on a side stream beside the quadtree: main-stream time = everything but the blur
-        match_ms = gpu_ms / args.steps - float(stage_ms.sum() - stage_ms[3])
+        match_ms = gpu_ms / args.steps - float(stage_ms.sum() - stage_ms[3]) if S == 1 else None
         dom = int(np.argmax(stage_ms))
         dom_name = names[dom]
         # the quadtree moves O(N) bytes; price it (if dominant) by the candidate bytes it gathers
-        dom_bytes = alg[dom_name] * B if alg[dom_name] else 4 * 4000 * B
+        dom_bytes = alg[dom_name] * Bs if alg[dom_name] else 4 * 4000 * Bs
         achieved = dom_bytes / (float(stage_ms[dom]) * 1e-3) / 1e9
         # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (same batch size only)
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pm.get("batch") == B:
+            if pm.get("batch") == Bs:
                 kk = pm["kernels"][{"pyramid": "k_pyr_resize", "fast_cells": "k_fast_cells", "octree": "k_octree", "blur": "k_blur",
                                     "describe": "k_describe"}[dom_name]]
                 traffic = (kk["FETCH_SIZE_KB_per_launch"] * kk.get("fetch_corr", 1.0) + kk["WRITE_SIZE_KB_per_launch"]) * 1024
@@ -209,13 +236,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": "TUM mono 640x480, 1000 features, 8 levels, scale 1.2, FAST 20/7: extract + "
                                    "SearchByProjection(Cur,Last) th=15 against the previous frame",
-                       "batch_per_gpu": B, "keypoints_per_frame": kp_mean, "matches_per_frame": nm_mean,
+                       "batch_per_gpu": B, "streams": S, "keypoints_per_frame": kp_mean, "matches_per_frame": nm_mean,
                        "parallelism": "frames sharded across %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": float(stage_ms[dom])},
             "stages_ms_per_step": dict({n: float(v) for n, v in zip(names, stage_ms)}, match=match_ms),
-            "extract_algorithmic_GBps": frame_alg * B / (float(stage_ms.sum()) * 1e-3) / 1e9,
+            "extract_algorithmic_GBps": frame_alg * Bs / (float(stage_ms.sum()) * 1e-3) / 1e9,
             "gpu_ms_per_step": gpu_ms / args.steps,
             "window_resolver_iterations_rescans": wstats,
             "single_frame_latency": latency,

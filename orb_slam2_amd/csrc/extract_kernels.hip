@@ -87,54 +87,62 @@ __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ i
 }
 
 // cv::resize INTER_LINEAR 8UC1 fixed-point arithmetic (called at :1550) from
-// level l-1 into level l.  A thread produces a 4 x 4 block of output pixels (64
-// independent source loads in flight, tap tables amortised over four rows, one
-// 32-bit store per row); the (row group, column group) index is flattened so
-// narrow levels do not leave lanes idle.
+// level l-1 into level l.  A workgroup produces a kRW x kRH output tile: the
+// source window of the tile is staged in LDS with coalesced 32-bit loads, then a
+// thread produces a 4 x 4 block of output pixels from LDS bytes (tap tables
+// amortised over four rows, one 32-bit store per row).
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, Geom G, int level,
                                                     const XTab *__restrict__ xtab, const YTab *__restrict__ ytab)
 {
+    extern __shared__ __align__(16) uint32_t rs_src[];
     const LevelGeom &gd = G.lv[level];
     const LevelGeom &gs = G.lv[level - 1];
-    const int gx = (gd.w + 3) >> 2, gy = (gd.h + 3) >> 2;
-    const int t = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    if (t >= gx * gy) return;
-    const int ry = t / gx, dx0 = (t - ry * gx) * 4, dy0 = ry * 4;
+    const int tilesX = (gd.w + kRW - 1) / kRW;
+    const int tyi = blockIdx.x / tilesX, ty0 = tyi * kRH, tx0 = (blockIdx.x - tyi * tilesX) * kRW;
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const XTab *xt = xtab + gd.xtab_off;
+    const YTab *yt = ytab + gd.ytab_off;
+    // source window: columns sx_al .. (last tap + 1), rows sy_min .. sy1 of the last output row
+    const int sx_al = xt[tx0].sx & ~3;
+    const int ndw = ((xt[min(tx0 + kRW - 1, gd.w - 1)].sx + 1 - sx_al) >> 2) + 1;
+    const int sy_min = yt[ty0].sy0;
+    const int nrows = yt[min(ty0 + kRH - 1, gd.h - 1)].sy1 - sy_min + 1;
+    const int P = gd.rs_pitch_dw;
     uint8_t *base = pyr + (int64_t)f * G.pyr_frame_bytes;
-    const uint8_t *S = base + interior_off(gs);
-    int sx[4], sx1[4], a0[4], a1[4];
+    const uint8_t *S = base + interior_off(gs) + (int64_t)sy_min * gs.pitch + sx_al;
+    const float inv_ndw = __fdiv_rn(1.0f, (float)ndw);
+    for (int i = tid; i < nrows * ndw; i += 256) {
+        const int r = (int)__fmul_rn((float)i + 0.5f, inv_ndw), c = i - r * ndw;  // exact: i < 2^16, ndw < 2^9
+        rs_src[r * P + c] = *reinterpret_cast<const uint32_t *>(S + (int64_t)r * gs.pitch + 4 * c);
+    }
+    __syncthreads();
+    const int dx0 = tx0 + 4 * (tid & 31), dy0 = ty0 + 4 * (tid >> 5);
+    if (dx0 >= gd.w || dy0 >= gd.h) return;
+    int xo[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const XTab xt = xtab[gd.xtab_off + min(dx0 + k, gd.w - 1)];
-        sx[k] = xt.sx;
-        sx1[k] = min(xt.sx + 1, gs.w - 1);
-        a0[k] = xt.a0;
-        a1[k] = xt.a1;
+        const XTab t = xt[min(dx0 + k, gd.w - 1)];
+        xo[k] = t.sx - sx_al;  // the right tap is the next byte: its weight is 0 where the reference clamps it
+        a0[k] = t.a0;
+        a1[k] = t.a1;
     }
-    YTab yt[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) yt[r] = ytab[gd.ytab_off + min(dy0 + r, gd.h - 1)];
-    uint32_t out[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint8_t *S0 = S + (int64_t)yt[r].sy0 * gs.pitch, *S1 = S + (int64_t)yt[r].sy1 * gs.pitch;
-        uint32_t v = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int r0 = S0[sx[k]] * a0[k] + S0[sx1[k]] * a1[k];
-            const int r1 = S1[sx[k]] * a0[k] + S1[sx1[k]] * a1[k];
-            const int px = (((yt[r].b0 * (r0 >> 4)) >> 16) + ((yt[r].b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            v |= (uint32_t)px << (8 * k);
-        }
-        out[r] = v;
-    }
+    const uint8_t *L = reinterpret_cast<const uint8_t *>(rs_src);
     const int n = min(4, gd.w - dx0);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        if (dy0 + r < gd.h) {
-            const uint32_t v[1] = {out[r]};
-            store_span_with_halo<1>(base + interior_off(gd), gd.pitch, gd.w, gd.h, dx0, dy0 + r, n, v);
+        if (dy0 + r >= gd.h) break;
+        const YTab y = yt[dy0 + r];
+        const uint8_t *R0 = L + (y.sy0 - sy_min) * P * 4, *R1 = L + (y.sy1 - sy_min) * P * 4;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r0 = R0[xo[k]] * a0[k] + R0[xo[k] + 1] * a1[k];
+            const int r1 = R1[xo[k]] * a0[k] + R1[xo[k] + 1] * a1[k];
+            const int px = (((y.b0 * (r0 >> 4)) >> 16) + ((y.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v |= (uint32_t)px << (8 * k);
         }
+        const uint32_t vv[1] = {v};
+        store_span_with_halo<1>(base + interior_off(gd), gd.pitch, gd.w, gd.h, dx0, dy0 + r, n, vv);
     }
 }
 
@@ -1009,8 +1017,8 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
         rows += (g.h + 2 * kEdge + 15) / 16;
-        hipLaunchKernelGGL(k_pyr_resize, dim3((((g.w + 3) / 4) * ((g.h + 3) / 4) + 255) / 256, nimg), dim3(256), 0, st, pyr, G, l, xtab,
-                           ytab);
+        hipLaunchKernelGGL(k_pyr_resize, dim3(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), nimg), dim3(256),
+                           (size_t)g.rs_rows * g.rs_pitch_dw * 4, st, pyr, G, l, xtab, ytab);
     }
     hipLaunchKernelGGL(k_halo_sides, dim3(rows, nimg), dim3(256), 0, st, pyr, G);
     ORBGPU_HIP_CHECK(hipGetLastError());

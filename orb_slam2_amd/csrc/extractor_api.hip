@@ -213,6 +213,25 @@ static int build_geometry(const orbgpu_extractor *e, int w, int h, Geom *G, std:
                 t.pad = 0;
                 yt->push_back(t);
             }
+            // source window staged by the largest kRW x kRH output tile (dword-aligned on the left)
+            const XTab *X = xt->data() + g.xtab_off;
+            const YTab *Y = yt->data() + g.ytab_off;
+            int maxdw = 1, maxrows = 1;
+            for (int tx0 = 0; tx0 < g.w; tx0 += kRW) {
+                const int last = X[tx0 + kRW - 1 < g.w ? tx0 + kRW - 1 : g.w - 1].sx + 1;
+                const int ndw = ((last - (X[tx0].sx & ~3)) >> 2) + 1;
+                maxdw = ndw > maxdw ? ndw : maxdw;
+            }
+            for (int ty0 = 0; ty0 < g.h; ty0 += kRH) {
+                const int rows = Y[ty0 + kRH - 1 < g.h ? ty0 + kRH - 1 : g.h - 1].sy1 - Y[ty0].sy0 + 1;
+                maxrows = rows > maxrows ? rows : maxrows;
+            }
+            g.rs_rows = maxrows;
+            g.rs_pitch_dw = maxdw | 1;
+            if ((int64_t)g.rs_rows * g.rs_pitch_dw * 4 > 64 * 1024) {
+                set_error("level %d: scale factor too large for the resize tile (%d x %d source dwords)", l, g.rs_rows, g.rs_pitch_dw);
+                return ORBGPU_E_UNSUPPORTED;
+            }
         }
     }
     G->total_cells = cells;

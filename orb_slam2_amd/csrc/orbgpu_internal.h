@@ -13,6 +13,7 @@ constexpr int kLeftMargin = 32;  // bytes in front of each interior row (>= kEdg
 constexpr int kMinBorder = 16;   // EDGE_THRESHOLD - 3: origin of the FAST search area
 constexpr int kMaxRoots = 16;    // initial quadtree nodes (round(width/height))
 constexpr int kMaxTile = 66;     // largest FAST cell incl. 3 px apron (cells are < 60 px)
+constexpr int kRW = 128, kRH = 32;  // output tile of one resize workgroup
 
 // Horizontal / vertical coefficient tables of the fixed-point bilinear resize.
 struct XTab { int32_t sx; int16_t a0, a1; };
@@ -40,6 +41,7 @@ struct LevelGeom {
     float hX;                // root width
     float scale;             // mvScaleFactor[level]
     int32_t patch_size;      // (int)(31*scale)
+    int32_t rs_rows, rs_pitch_dw;  // resize into this level: staged source rows / dwords per row of the largest tile
     int64_t plane_off;       // byte offset of the level's allocation within a frame's pyramid
     int64_t slot_off;        // u32 offset of the level's cell slots within a frame
     int64_t cand_off;        // u32 offset of the level's candidate arrays within a frame
