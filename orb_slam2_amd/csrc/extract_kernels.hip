@@ -898,110 +898,196 @@ __device__ __forceinline__ void sincos_rounded(float x, float *s, float *c)
     *c = (float)cv;
 }
 
+// Sum over the wave with DPP lane permutations; the result is uniform.
+__device__ __forceinline__ int wave_sum_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+constexpr int kDescGroup = 16;  // keypoint slots per wave
+constexpr int kBR = 18;         // largest rotated pattern coordinate: round(hypot(13, 13))
+constexpr int kBPitch = 40;     // bytes per staged row of the blurred patch: 37 + up to 3 of alignment
+
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, Geom G,
                                                   const uint32_t *__restrict__ sel, const int32_t *__restrict__ sel_count,
                                                   const int8_t *__restrict__ pattern, orbgpu_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int capacity,
                                                   int32_t *__restrict__ status)
 {
+    // A wave owns kDescGroup consecutive keypoint slots.  Stage A: intensity
+    // centroid of each (aligned 32-bit loads, dot products against per-lane
+    // weights).  Stage B: lane j turns the moments of keypoint j into angle,
+    // sine and cosine -- once for the whole group.  Stage C: the blurred patch
+    // of each keypoint goes through LDS and the 256 tests read it from there.
+    __shared__ __align__(16) uint8_t patch[4][(2 * kBR + 1) * kBPitch];
     const int f = blockIdx.y, lane = lane_id();
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slot >= G.total_kp_cap) return;
-    int l = 0;
-    while (l + 1 < G.nlevels && slot >= G.lv[l + 1].kp_off) l++;
-    const LevelGeom &g = G.lv[l];
-    const int i = slot - g.kp_off;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot0 = (blockIdx.x * 4 + wv) * kDescGroup;
+    if (slot0 >= G.total_kp_cap) return;
     const int32_t *sc = sel_count + f * G.nlevels;
-    int off = 0, total = 0;
-    for (int k = 0; k < G.nlevels; k++) {
-        const int n = sc[k];
-        if (k < l) off += n;
-        total += n;
-    }
-    if (slot == 0 && lane == 0) {
-        counts[f] = min(total, capacity);
-        if (total > capacity) atomicOr(status, 2);
-    }
-    if (i >= sc[l]) return;
-    const int oi = off + i;
-    if (oi >= capacity) return;
 
-    // the sampling pattern does not depend on anything: fetch it first
+    // lane j < kDescGroup: geometry of slot slot0 + j
+    int my_l = 0, my_valid = 0, my_oi = 0, my_x = kEdge, my_y = kEdge, my_resp = 0;
+    {
+        const int slot = slot0 + (lane & (kDescGroup - 1));
+        int off = 0, total = 0, l = 0, offl = 0;
+        for (int k = 0; k < G.nlevels; k++) {
+            const int n = sc[k];
+            if (k + 1 < G.nlevels && slot >= G.lv[k + 1].kp_off) { l = k + 1; offl = off + n; }
+            off += n;
+            total += n;
+        }
+        if (slot0 == 0 && lane == 0) {
+            counts[f] = min(total, capacity);
+            if (total > capacity) atomicOr(status, 2);
+        }
+        const int i = slot - G.lv[l].kp_off;
+        my_oi = offl + i;
+        if (slot < G.total_kp_cap && i < sc[l] && my_oi < capacity) {
+            const uint32_t p = sel[(int64_t)f * G.total_kp_cap + slot];
+            my_l = l;
+            my_valid = 1;
+            my_x = cand_x(p) + kMinBorder;  // level coordinates (:1129-1130)
+            my_y = cand_y(p) + kMinBorder;
+            my_resp = cand_s(p);
+        }
+    }
+    if (__ballot(my_valid && lane < kDescGroup) == 0) return;
+    // invalid slots compute on pixel (19, 19) of level 0 and store nothing
+    int my_pitch = 0, my_off = 0;
+    for (int k = 0; k < G.nlevels; k++)
+        if (k == my_l) {
+            my_pitch = G.lv[k].pitch;
+            my_off = (int)(interior_off(G.lv[k]) + (int64_t)my_y * G.lv[k].pitch + my_x);
+        }
+    const uint8_t *fpyr = pyr + (int64_t)f * G.pyr_frame_bytes, *fblur = blur + (int64_t)f * G.pyr_frame_bytes;
+
+    // ---- stage A: m10 = sum u*I, m01 = sum v*I over the disc (:85-130) -----------------
+    // the 31 x 32 px bounding box is 248 dwords (v = -15..15, u = -15+4j .. -12+4j); lane owns 4 of them
+    int icv[4], icu0[4];
+    uint32_t wU[4], wM[4];
+    {
+        const unsigned long long umax_nibbles = 0x3689ABCDDEEEFFFFull;  // umax[v] = nibble v: 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int p = lane + 64 * m;
+            const bool live = p < 248;
+            const int v = live ? (p >> 3) - 15 : 0, u0 = live ? -15 + 4 * (p & 7) : -15;  // idle lanes re-read an aligned dword, weight 0
+            const int um = (int)((umax_nibbles >> (4 * (v < 0 ? -v : v))) & 15ull);
+            uint32_t a = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int u = u0 + k;
+                const bool in = live && u >= -um && u <= um;
+                a |= (in ? (uint32_t)(u + 15) : 0u) << (8 * k);
+                b |= (in ? 1u : 0u) << (8 * k);
+            }
+            icv[m] = v; icu0[m] = u0; wU[m] = a; wM[m] = b;
+        }
+    }
+    int my_m10 = 0, my_m01 = 0;
+#pragma unroll 4
+    for (int j = 0; j < kDescGroup; j++) {
+        const int pitch = __builtin_amdgcn_readlane(my_pitch, j), off = __builtin_amdgcn_readlane(my_off, j);
+        const int sh = (off - 15) & 3;  // planes are 4-byte aligned: the alignment of x - 15 is that of its byte offset
+        const uint8_t *c = fpyr + off - sh;
+        int sU = 0, sM = 0, sV = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(c + icv[m] * pitch + icu0[m]);
+            const uint32_t px = __builtin_amdgcn_alignbyte(q[1], q[0], sh);
+            const int msum = (int)__builtin_amdgcn_udot4(px, wM[m], 0u, false);
+            sU = (int)__builtin_amdgcn_udot4(px, wU[m], (uint32_t)sU, false);
+            sM += msum;
+            sV += icv[m] * msum;
+        }
+        const int m10 = wave_sum_dpp(sU - 15 * sM), m01 = wave_sum_dpp(sV);
+        if (lane == j) { my_m10 = m10; my_m01 = m01; }
+    }
+
+    // ---- stage B: orientation, once per group ---------------------------------------------
+    const float my_angle = fast_atan2_deg((float)my_m01, (float)my_m10);
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
+    float my_a, my_b;
+    sincos_rounded(__fmul_rn(my_angle, factorPI), &my_b, &my_a);
+    if (lane < kDescGroup && my_valid) {
+        orbgpu_keypoint k;
+        const float fx = (float)my_x, fy = (float)my_y;
+        float scale = 1.0f;
+        int psize = 31;
+        for (int q = 0; q < G.nlevels; q++)
+            if (q == my_l) { scale = G.lv[q].scale; psize = G.lv[q].patch_size; }
+        k.x = my_l ? __fmul_rn(fx, scale) : fx;
+        k.y = my_l ? __fmul_rn(fy, scale) : fy;
+        k.size = (float)psize;
+        k.angle = my_angle;
+        k.response = (float)my_resp;
+        k.octave = my_l;
+        k.class_id = -1;
+        kps[(int64_t)f * capacity + my_oi] = k;
+    }
+
+    // ---- stage C: steered BRIEF on the blurred level (:142-191) -----------------------------
     char4 pt[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) pt[k] = reinterpret_cast<const char4 *>(pattern)[k * 64 + lane];
-    const uint32_t p = sel[(int64_t)f * G.total_kp_cap + slot];
-    const int x = cand_x(p) + kMinBorder, y = cand_y(p) + kMinBorder;  // level coordinates (:1129-1130)
-    const uint8_t *img = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch + x;
-
-    // intensity centroid over the circular patch: two rows per step, all 16
-    // loads issued back to back (lanes outside the disc read the centre, weight 0)
-    int m10 = 0, m01 = 0;
+    // staging: 37 rows x 10 dwords = 370 dwords, lane owns 6 of them
+    int srow[6], scol[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+        const int i = min(lane + 64 * m, (2 * kBR + 1) * (kBPitch / 4) - 1);
+        srow[m] = i / (kBPitch / 4);
+        scol[m] = i - srow[m] * (kBPitch / 4);
+    }
+    uint32_t *pw = reinterpret_cast<uint32_t *>(patch[wv]);
+    const uint8_t *pb = patch[wv];
+    uint32_t pre[6];
     {
-        const int half = lane >> 5, u = (lane & 31) - 15;
-        const unsigned long long umax_nibbles = 0x3689ABCDDEEEFFFFull;  // umax[v] = nibble v: 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3
-        int I[16], wu[16], wv[16];
+        const int pitch = __builtin_amdgcn_readlane(my_pitch, 0), off = __builtin_amdgcn_readlane(my_off, 0);
+        const uint8_t *c = fblur + off - kBR * pitch - kBR - ((off - kBR) & 3);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int v = -15 + 2 * r + half;
-            const int av = v < 0 ? -v : v;
-            const int um = (int)((umax_nibbles >> (4 * (av & 15))) & 15ull);
-            const bool in = v <= 15 && u >= -um && u <= um;
-            I[r] = img[in ? v * g.pitch + u : 0];
-            wu[r] = in ? u : 0;
-            wv[r] = in ? v : 0;
+        for (int m = 0; m < 6; m++) pre[m] = *reinterpret_cast<const uint32_t *>(c + srow[m] * pitch + 4 * scol[m]);
+    }
+    for (int j = 0; j < kDescGroup; j++) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) pw[srow[m] * (kBPitch / 4) + scol[m]] = pre[m];
+        const int ox = (__builtin_amdgcn_readlane(my_off, j) - kBR) & 3;
+        if (j + 1 < kDescGroup) {
+            const int pitch = __builtin_amdgcn_readlane(my_pitch, j + 1), off = __builtin_amdgcn_readlane(my_off, j + 1);
+            const uint8_t *c = fblur + off - kBR * pitch - kBR - ((off - kBR) & 3);
+#pragma unroll
+            for (int m = 0; m < 6; m++) pre[m] = *reinterpret_cast<const uint32_t *>(c + srow[m] * pitch + 4 * scol[m]);
         }
+        __builtin_amdgcn_wave_barrier();
+        const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_a), j));
+        const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_b), j));
+        const uint8_t *ctr = pb + kBR * kBPitch + kBR + ox;
+        int tap0[4], tap1[4];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            m10 += wu[r] * I[r];
-            m01 += wv[r] * I[r];
+        for (int k = 0; k < 4; k++) {
+            const float x0 = (float)pt[k].x, y0 = (float)pt[k].y, x1 = (float)pt[k].z, y1 = (float)pt[k].w;
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+            const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+            const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+            tap0[k] = ctr[r0 * kBPitch + q0];
+            tap1[k] = ctr[r1 * kBPitch + q1];
         }
+        uint64_t bits[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o);
-            m01 += __shfl_xor(m01, o);
+        for (int k = 0; k < 4; k++) bits[k] = __ballot(tap0[k] < tap1[k]);
+        __builtin_amdgcn_wave_barrier();
+        const int valid = __builtin_amdgcn_readlane(my_valid, j), oi = __builtin_amdgcn_readlane(my_oi, j);
+        if (valid && lane < 4) {
+            const uint64_t w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+            reinterpret_cast<uint64_t *>(desc + ((int64_t)f * capacity + oi) * 32)[lane] = w;
         }
-    }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    // steered BRIEF on the blurred level: 8 taps per lane, loads batched
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
-    const float ang = __fmul_rn(angle, factorPI);
-    float a, b;
-    sincos_rounded(ang, &b, &a);
-    const uint8_t *bl = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch + x;
-    uint64_t bits[4];
-    int tap0[4], tap1[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float x0 = (float)pt[k].x, y0 = (float)pt[k].y, x1 = (float)pt[k].z, y1 = (float)pt[k].w;
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        tap0[k] = bl[r0 * g.pitch + q0];
-        tap1[k] = bl[r1 * g.pitch + q1];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int t0 = tap0[k], t1 = tap1[k];
-        bits[k] = __ballot(t0 < t1);
-    }
-    if (lane < 4) {
-        const uint64_t w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        reinterpret_cast<uint64_t *>(desc + ((int64_t)f * capacity + oi) * 32)[lane] = w;
-    }
-    if (lane == 0) {
-        orbgpu_keypoint k;
-        const float fx = (float)x, fy = (float)y;
-        k.x = l ? __fmul_rn(fx, g.scale) : fx;
-        k.y = l ? __fmul_rn(fy, g.scale) : fy;
-        k.size = (float)g.patch_size;
-        k.angle = angle;
-        k.response = (float)cand_s(p);
-        k.octave = l;
-        k.class_id = -1;
-        kps[(int64_t)f * capacity + oi] = k;
     }
 }
 
@@ -1063,7 +1149,7 @@ int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t 
                     const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
                     int capacity, int32_t *status)
 {
-    hipLaunchKernelGGL(k_describe, dim3((G.total_kp_cap + 3) / 4, nimg), dim3(256), 0, st, pyr, blur, G, sel, sel_count,
+    hipLaunchKernelGGL(k_describe, dim3((G.total_kp_cap + 4 * kDescGroup - 1) / (4 * kDescGroup), nimg), dim3(256), 0, st, pyr, blur, G, sel, sel_count,
                        pattern, kps, desc, counts, capacity, status);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
