@@ -42,8 +42,9 @@ __device__ __forceinline__ void store_span_with_halo(uint8_t *in, int pitch, int
 // one thread per pixel, all levels in one launch.
 __global__ __launch_bounds__(256) void k_halo_sides(uint8_t *__restrict__ pyr, Geom G)
 {
-    const int f = blockIdx.y;
-    int l = 0, b = blockIdx.x;  // a workgroup = 16 rows (38 columns padded to 64 lanes) of one level
+    int f, b;  // a workgroup = 16 rows (38 columns padded to 64 lanes) of one level
+    if (!frame_block(G.nimg, &f, &b)) return;
+    int l = 0;
     while (true) {
         const int n = (G.lv[l].h + 2 * kEdge + 15) >> 4;
         if (b < n) break;
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ i
                                                    uint8_t *__restrict__ pyr, Geom G)
 {
     const LevelGeom &g = G.lv[0];
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 16, y = blockIdx.y, f = blockIdx.z;
+    int f, b;
+    if (!frame_block(G.nimg, &f, &b)) return;
+    const int y = b % g.h, x = ((b / g.h) * 256 + threadIdx.x) * 16;
     if (x >= g.w) return;
     const uint8_t *src = img + (size_t)f * frame_stride + (size_t)y * stride + x;
     const int n = min(16, g.w - x);
@@ -98,8 +101,10 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
     const LevelGeom &gd = G.lv[level];
     const LevelGeom &gs = G.lv[level - 1];
     const int tilesX = (gd.w + kRW - 1) / kRW;
-    const int tyi = blockIdx.x / tilesX, ty0 = tyi * kRH, tx0 = (blockIdx.x - tyi * tilesX) * kRW;
-    const int f = blockIdx.y, tid = threadIdx.x;
+    int f, b;
+    if (!frame_block(G.nimg, &f, &b)) return;
+    const int tyi = b / tilesX, ty0 = tyi * kRH, tx0 = (b - tyi * tilesX) * kRW;
+    const int tid = threadIdx.x;
     const XTab *xt = xtab + gd.xtab_off;
     const YTab *yt = ytab + gd.ytab_off;
     // source window: columns sx_al .. (last tap + 1), rows sy_min .. sy1 of the last output row
@@ -183,21 +188,23 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
 // i / d for 0 <= i < 4096, 1 <= d <= 66, with m = ceil(2^20 / d)
 __device__ __forceinline__ int div_small(int i, int m) { return (int)(((unsigned)i * (unsigned)m) >> 20); }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G,
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G, const uint32_t *__restrict__ cell_tab,
                                                     uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts)
 {
     __shared__ __align__(16) uint8_t tile[kMaxTile * kTP];
     __shared__ __align__(16) uint8_t score[(kMaxTile - 4) * kTP];  // interior + 1 px zero border
-    __shared__ __align__(16) uint8_t flag[(kMaxTile - 6) * (kMaxTile - 6) + 16];  // row-major over the interior
     __shared__ uint16_t queue[(kMaxTile - 6) * (kMaxTile - 6)];
-    __shared__ int qn;
-    __shared__ int scan_lds[33];
+    __shared__ uint32_t maxima[(kMaxTile - 5) * (kMaxTile - 5) / 4];  // strict 3x3 maxima are never adjacent
+    __shared__ int qn, nmax, nini;
 
-    const int f = blockIdx.y, cell = blockIdx.x, tid = threadIdx.x;
-    int l = 0;
-    while (l + 1 < G.nlevels && cell >= G.lv[l + 1].cell_off) l++;
+    int f, cell;
+    if (!frame_block(G.nimg, &f, &cell)) return;
+    const int tid = threadIdx.x;
+    // cell_tab: level | cell row << 8 | cell column << 20
+    const uint32_t ct = cell_tab[cell];
+    const int l = ct & 0xFF, ci_i = (ct >> 8) & 0xFFF, ci_j = ct >> 20;
     const LevelGeom &g = G.lv[l];
-    const int ci = cell - g.cell_off, ci_i = ci / g.nCols, ci_j = ci - ci_i * g.nCols;
+    const int ci = cell - g.cell_off;
     const int maxBX = g.w - kMinBorder, maxBY = g.h - kMinBorder;
     const int iniY = kMinBorder + ci_i * g.hCell, iniX = kMinBorder + ci_j * g.wCell;
     int32_t *cnt_out = cell_counts + (int64_t)f * G.total_cells + cell;
@@ -223,15 +230,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
             for (int r = r0; r < ch; r += 8)
                 reinterpret_cast<uint32_t *>(tile)[r * (kTP / 4) + c] = *reinterpret_cast<const uint32_t *>(src + (int64_t)r * g.pitch + 4 * c);
     }
-    for (int i = tid; i < (hi + 2) * (kTP / 4); i += 256) reinterpret_cast<uint32_t *>(score)[i] = 0;
-    const int npix = wi * hi;
-    for (int i = tid; i < ((npix + 15) >> 2); i += 256) reinterpret_cast<uint32_t *>(flag)[i] = 0;
-    if (tid == 0) qn = 0;
+    for (int i = tid; i < ((hi + 2) * (kTP / 4) + 3) / 4; i += 256) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) { qn = 0; nmax = 0; nini = 0; }
     __syncthreads();
 
     // stage 1: cheap rejection at the lower threshold; survivors are compacted
     // into a queue so the expensive arc evaluation runs on dense waves.
     const int t = G.minTh;
+    const int npix = wi * hi;
     const int mdiv = ((1 << 20) + wi - 1) / wi;
     const uint8_t *t0 = tile + ox;  // pixel (x, y) of the cell image is t0[y * kTP + x]
     for (int i = tid; i < npix; i += 256) {
@@ -241,9 +247,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
         // any 9-long arc contains one pixel of each opposite pair (k, k+8)
         const int p0 = c[3 * kTP], p8 = c[-3 * kTP], p4 = c[3], p12 = c[-3];
         const int p2 = c[2 * kTP + 2], p10 = c[-2 * kTP - 2], p6 = c[-2 * kTP + 2], p14 = c[2 * kTP - 2];
-        const bool dark = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo) && (p2 < lo || p10 < lo) && (p6 < lo || p14 < lo);
-        const bool bright = (p0 > hi_ || p8 > hi_) && (p4 > hi_ || p12 > hi_) && (p2 > hi_ || p10 > hi_) && (p6 > hi_ || p14 > hi_);
-        if (dark || bright) queue[atomicAdd(&qn, 1)] = (uint16_t)i;
+        const int dmax = max(max(min(p0, p8), min(p4, p12)), max(min(p2, p10), min(p6, p14)));
+        const int bmin = min(min(max(p0, p8), max(p4, p12)), min(max(p2, p10), max(p6, p14)));
+        if (dmax < lo || bmin > hi_) queue[atomicAdd(&qn, 1)] = (uint16_t)i;
     }
     __syncthreads();
     const int nq = qn;
@@ -254,52 +260,41 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
         if (A > t) score[(y + 1) * kTP + (x + 1)] = (uint8_t)(A - 1);
     }
     __syncthreads();
-    // stage 2: strict 3x3 maximum inside the cell, evaluated for the corners only
+    // stage 2: strict 3x3 maximum inside the cell, evaluated for the corners only;
+    // a maximum is listed as pixel index | initial-threshold flag << 12 | score << 16
     for (int q = tid; q < nq; q += 256) {
         const int i = queue[q];
         const int y = div_small(i, mdiv), x = i - y * wi;
         const uint8_t *s = score + (y + 1) * kTP + (x + 1);
         const int sc = s[0];
         if (sc == 0) continue;
-        const bool ismax = sc > s[-1] && sc > s[1] && sc > s[-kTP - 1] && sc > s[-kTP] && sc > s[-kTP + 1] &&
-                           sc > s[kTP - 1] && sc > s[kTP] && sc > s[kTP + 1];
-        if (ismax) flag[i] = (uint8_t)(1 | (sc >= G.iniTh ? 2 : 0));
+        const int nb = max(max(max((int)s[-1], (int)s[1]), max((int)s[-kTP - 1], (int)s[-kTP])),
+                           max(max((int)s[-kTP + 1], (int)s[kTP - 1]), max((int)s[kTP], (int)s[kTP + 1])));
+        if (sc > nb) {
+            const int ini = sc >= G.iniTh ? 1 : 0;
+            maxima[atomicAdd(&nmax, 1)] = (uint32_t)i | ((uint32_t)ini << 12) | ((uint32_t)sc << 16);
+            if (ini) atomicAdd(&nini, 1);
+        }
     }
     __syncthreads();
 
-    // stage 3: threshold choice and ordered (row-major) emission; a thread owns
-    // a run of `per` consecutive pixels (a multiple of 4: whole flag dwords)
-    const int per = ((npix + 1023) >> 10) << 2;
-    const int p0i = tid * per;
-    uint32_t mmax = 0, mini = 0;
-    if (p0i < npix) {
-        for (int w = 0; w < (per >> 2); w++) {
-            const uint32_t fw = reinterpret_cast<const uint32_t *>(flag)[(p0i >> 2) + w];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t b = (fw >> (8 * k)) & 3u;
-                mmax |= (b & 1u) << (4 * w + k);
-                mini |= (b >> 1) << (4 * w + k);
-            }
-        }
-    }
-    int total;
-    const int packed = __popc(mini) | (__popc(mmax) << 16);
-    const int excl = block_scan_excl(packed, &total, scan_lds);
-    const bool use_ini = (total & 0xFFFF) > 0;
-    uint32_t m = use_ini ? mini : mmax;
-    int pos = use_ini ? (excl & 0xFFFF) : (excl >> 16);
-    const int count = use_ini ? (total & 0xFFFF) : (total >> 16);
+    // stage 3: threshold choice (:1071-1082) and row-major emission: the position of
+    // a maximum in the output is its rank by pixel index among the chosen ones
+    const int n = nmax, use_ini = nini > 0;
+    const int count = use_ini ? nini : n;
     uint32_t *slot = slots + (int64_t)f * G.slot_frame_u32 + g.slot_off + (int64_t)ci * g.cell_cap;
-    while (m) {
-        const int k = __ffs((int)m) - 1;
-        m &= m - 1;
-        const int i = p0i + k;
-        const int y = div_small(i, mdiv), x = i - y * wi;
-        const int sc = score[(y + 1) * kTP + (x + 1)];
+    for (int k = tid; k < n; k += 256) {
+        const uint32_t e = maxima[k];
+        if (use_ini && !(e & 0x1000u)) continue;
+        const uint32_t need = use_ini ? 0x1000u : 0u, pix = e & 0xFFFu;
+        int pos = 0;
+        for (int j = 0; j < n; j++) {
+            const uint32_t o = maxima[j];
+            pos += ((o & 0x1000u) >= need && (o & 0xFFFu) < pix) ? 1 : 0;
+        }
+        const int y = div_small((int)pix, mdiv), x = (int)pix - y * wi;
         // keypoint coordinates relative to (16,16): sub-image x (+3 apron) + j*wCell (:1099-1100)
-        if (pos < g.cell_cap) slot[pos] = pack_cand(x + 3 + ci_j * g.wCell, y + 3 + ci_i * g.hCell, sc);
-        pos++;
+        if (pos < g.cell_cap) slot[pos] = pack_cand(x + 3 + ci_j * g.wCell, y + 3 + ci_i * g.hCell, (int)(e >> 16));
     }
     if (tid == 0) *cnt_out = min(count, g.cell_cap);
 }
@@ -783,8 +778,10 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 {
     __shared__ uint32_t src[(kBH + 6) * kBSrcDw];
     __shared__ uint16_t hrow[(kBH + 6) * kBW];
-    const int f = blockIdx.y, tid = threadIdx.x;
-    int l = 0, t = blockIdx.x;
+    int f, t;
+    if (!frame_block(G.nimg, &f, &t)) return;
+    const int tid = threadIdx.x;
+    int l = 0;
     while (true) {
         const int n = ((G.lv[l].w + kBW - 1) / kBW) * ((G.lv[l].h + kBH - 1) / kBH);
         if (t < n) break;
@@ -910,7 +907,9 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-constexpr int kDescGroup = 16;  // keypoint slots per wave
+struct __attribute__((aligned(4))) DwordPair { uint32_t lo, hi; };  // one 64-bit load at 32-bit alignment
+
+constexpr int kDescGroup = 8;   // keypoint slots per wave
 constexpr int kBR = 18;         // largest rotated pattern coordinate: round(hypot(13, 13))
 constexpr int kBPitch = 40;     // bytes per staged row of the blurred patch: 37 + up to 3 of alignment
 
@@ -926,30 +925,42 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     // sine and cosine -- once for the whole group.  Stage C: the blurred patch
     // of each keypoint goes through LDS and the 256 tests read it from there.
     __shared__ __align__(16) uint8_t patch[4][(2 * kBR + 1) * kBPitch];
-    const int f = blockIdx.y, lane = lane_id();
+    int f, blk;
+    if (!frame_block(G.nimg, &f, &blk)) return;
+    const int lane = lane_id();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot0 = (blockIdx.x * 4 + wv) * kDescGroup;
+    const int slot0 = (blk * 4 + wv) * kDescGroup;
     if (slot0 >= G.total_kp_cap) return;
     const int32_t *sc = sel_count + f * G.nlevels;
 
-    // lane j < kDescGroup: geometry of slot slot0 + j
+    // lane j < kDescGroup: geometry of slot slot0 + j (invalid slots compute on pixel (19, 19) of
+    // level 0 and store nothing); every table below is read with uniform, independent loads
     int my_l = 0, my_valid = 0, my_oi = 0, my_x = kEdge, my_y = kEdge, my_resp = 0;
+    int my_pitch, my_off, my_patch;
+    float my_scale;
     {
         const int slot = slot0 + (lane & (kDescGroup - 1));
-        int off = 0, total = 0, l = 0, offl = 0;
-        for (int k = 0; k < G.nlevels; k++) {
-            const int n = sc[k];
-            if (k + 1 < G.nlevels && slot >= G.lv[k + 1].kp_off) { l = k + 1; offl = off + n; }
-            off += n;
-            total += n;
+        int n[ORBGPU_MAX_LEVELS];
+#pragma unroll
+        for (int k = 0; k < ORBGPU_MAX_LEVELS; k++) n[k] = sc[k];  // entries past nlevels belong to later frames: masked below
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < ORBGPU_MAX_LEVELS; k++) l += slot >= G.t_kp_off[k] ? 1 : 0;  // unused levels hold INT_MAX
+        int total = 0, offl = 0, nl = 0, kpo = 0;
+#pragma unroll
+        for (int k = 0; k < ORBGPU_MAX_LEVELS; k++) {
+            const int nk = k < G.nlevels ? n[k] : 0;
+            total += nk;
+            offl += k < l ? nk : 0;
+            if (k == l) { nl = nk; kpo = G.t_kp_off[k]; }
         }
         if (slot0 == 0 && lane == 0) {
             counts[f] = min(total, capacity);
             if (total > capacity) atomicOr(status, 2);
         }
-        const int i = slot - G.lv[l].kp_off;
+        const int i = slot - kpo;
         my_oi = offl + i;
-        if (slot < G.total_kp_cap && i < sc[l] && my_oi < capacity) {
+        if (slot < G.total_kp_cap && i < nl && my_oi < capacity) {
             const uint32_t p = sel[(int64_t)f * G.total_kp_cap + slot];
             my_l = l;
             my_valid = 1;
@@ -957,15 +968,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             my_y = cand_y(p) + kMinBorder;
             my_resp = cand_s(p);
         }
+        my_pitch = G.t_pitch[0]; my_off = G.t_interior[0]; my_patch = G.t_patch[0]; my_scale = G.t_scale[0];
+#pragma unroll
+        for (int k = 1; k < ORBGPU_MAX_LEVELS; k++)
+            if (k == my_l) { my_pitch = G.t_pitch[k]; my_off = G.t_interior[k]; my_patch = G.t_patch[k]; my_scale = G.t_scale[k]; }
+        my_off += my_y * my_pitch + my_x;
     }
     if (__ballot(my_valid && lane < kDescGroup) == 0) return;
-    // invalid slots compute on pixel (19, 19) of level 0 and store nothing
-    int my_pitch = 0, my_off = 0;
-    for (int k = 0; k < G.nlevels; k++)
-        if (k == my_l) {
-            my_pitch = G.lv[k].pitch;
-            my_off = (int)(interior_off(G.lv[k]) + (int64_t)my_y * G.lv[k].pitch + my_x);
-        }
     const uint8_t *fpyr = pyr + (int64_t)f * G.pyr_frame_bytes, *fblur = blur + (int64_t)f * G.pyr_frame_bytes;
 
     // ---- stage A: m10 = sum u*I, m01 = sum v*I over the disc (:85-130) -----------------
@@ -1000,8 +1009,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         int sU = 0, sM = 0, sV = 0;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(c + icv[m] * pitch + icu0[m]);
-            const uint32_t px = __builtin_amdgcn_alignbyte(q[1], q[0], sh);
+            const DwordPair q = *reinterpret_cast<const DwordPair *>(c + icv[m] * pitch + icu0[m]);
+            const uint32_t px = __builtin_amdgcn_alignbyte(q.hi, q.lo, sh);
             const int msum = (int)__builtin_amdgcn_udot4(px, wM[m], 0u, false);
             sU = (int)__builtin_amdgcn_udot4(px, wU[m], (uint32_t)sU, false);
             sM += msum;
@@ -1019,13 +1028,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     if (lane < kDescGroup && my_valid) {
         orbgpu_keypoint k;
         const float fx = (float)my_x, fy = (float)my_y;
-        float scale = 1.0f;
-        int psize = 31;
-        for (int q = 0; q < G.nlevels; q++)
-            if (q == my_l) { scale = G.lv[q].scale; psize = G.lv[q].patch_size; }
-        k.x = my_l ? __fmul_rn(fx, scale) : fx;
-        k.y = my_l ? __fmul_rn(fy, scale) : fy;
-        k.size = (float)psize;
+        k.x = my_l ? __fmul_rn(fx, my_scale) : fx;
+        k.y = my_l ? __fmul_rn(fy, my_scale) : fy;
+        k.size = (float)my_patch;
         k.angle = my_angle;
         k.response = (float)my_resp;
         k.octave = my_l;
@@ -1095,25 +1100,30 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 // host-side launchers
 // ---------------------------------------------------------------------------
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
-                   const Geom &G, const XTab *xtab, const YTab *ytab)
+                   const Geom &G_, const XTab *xtab, const YTab *ytab)
 {
+    // the XCD-pinned frame mapping (nimg >= 8) pays off for the kernels that re-read shared rows
+    // (resize, blur, describe); the streaming ones keep the plain mapping (nimg = 0)
+    Geom G = G_;
+    G.nimg = nimg;
     const LevelGeom &g0 = G.lv[0];
-    hipLaunchKernelGGL(k_pyr_copy0, dim3((g0.w + 4095) / 4096, g0.h, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G);
+    hipLaunchKernelGGL(k_pyr_copy0, dim3(((g0.w + 4095) / 4096) * g0.h, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G_);
     int rows = (g0.h + 2 * kEdge + 15) / 16;
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
         rows += (g.h + 2 * kEdge + 15) / 16;
-        hipLaunchKernelGGL(k_pyr_resize, dim3(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), nimg), dim3(256),
+        hipLaunchKernelGGL(k_pyr_resize, dim3(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), grid_frames(nimg)), dim3(256),
                            (size_t)g.rs_rows * g.rs_pitch_dw * 4, st, pyr, G, l, xtab, ytab);
     }
-    hipLaunchKernelGGL(k_halo_sides, dim3(rows, nimg), dim3(256), 0, st, pyr, G);
+    hipLaunchKernelGGL(k_halo_sides, dim3(rows, nimg), dim3(256), 0, st, pyr, G_);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
 
-int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, uint32_t *slots, int32_t *cell_counts)
+int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
+                int32_t *cell_counts)
 {
-    hipLaunchKernelGGL(k_fast_cells, dim3(G.total_cells, nimg), dim3(256), 0, st, pyr, G, slots, cell_counts);
+    hipLaunchKernelGGL(k_fast_cells, dim3(G.total_cells, nimg), dim3(256), 0, st, pyr, G, cell_tab, slots, cell_counts);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
@@ -1136,20 +1146,25 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     return ORBGPU_OK;
 }
 
-int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G)
+int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G_)
 {
+    Geom G = G_;
+    G.nimg = nimg;
     int tiles = 0;
     for (int l = 0; l < G.nlevels; l++) tiles += ((G.lv[l].w + kBW - 1) / kBW) * ((G.lv[l].h + kBH - 1) / kBH);
-    hipLaunchKernelGGL(k_blur, dim3(tiles, nimg), dim3(256), 0, st, pyr, blur, G);
+    hipLaunchKernelGGL(k_blur, dim3(tiles, grid_frames(nimg)), dim3(256), 0, st, pyr, blur, G);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
 
-int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t *blur, const Geom &G, const uint32_t *sel,
+int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t *blur, const Geom &G_, const uint32_t *sel,
                     const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
                     int capacity, int32_t *status)
 {
-    hipLaunchKernelGGL(k_describe, dim3((G.total_kp_cap + 4 * kDescGroup - 1) / (4 * kDescGroup), nimg), dim3(256), 0, st, pyr, blur, G, sel, sel_count,
+    Geom G = G_;
+    G.nimg = nimg;
+    hipLaunchKernelGGL(k_describe, dim3((G.total_kp_cap + 4 * kDescGroup - 1) / (4 * kDescGroup), grid_frames(nimg)), dim3(256), 0, st, pyr,
+                       blur, G, sel, sel_count,
                        pattern, kps, desc, counts, capacity, status);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;

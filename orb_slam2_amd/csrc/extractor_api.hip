@@ -24,7 +24,8 @@ void set_error(const char *fmt, ...)
 
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
                    const Geom &G, const XTab *xtab, const YTab *ytab);
-int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, uint32_t *slots, int32_t *cell_counts);
+int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
+                int32_t *cell_counts);
 int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
                   QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status);
 int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G);
@@ -77,7 +78,7 @@ struct orbgpu_extractor {
     Geom G;
     int geom_w = 0, geom_h = 0;
     int last_nimg = 0;
-    DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab;
+    DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab, cell_tab;
     DevBuf st_img, st_kps, st_desc, st_counts;  // staging for the host entry points
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
@@ -234,6 +235,18 @@ static int build_geometry(const orbgpu_extractor *e, int w, int h, Geom *G, std:
             }
         }
     }
+    for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) {
+        const LevelGeom &g = G->lv[l < L ? l : L - 1];
+        G->t_kp_off[l] = l < L ? g.kp_off : 0x7FFFFFFF;
+        G->t_pitch[l] = g.pitch;
+        G->t_interior[l] = (int32_t)interior_off(g);
+        G->t_patch[l] = g.patch_size;
+        G->t_scale[l] = g.scale;
+    }
+    if (pyr + 64 > 0x7FFFFFFF) {
+        set_error("pyramid of one frame exceeds 2 GiB");
+        return ORBGPU_E_UNSUPPORTED;
+    }
     G->total_cells = cells;
     G->total_kp_cap = kp;
     G->pyr_frame_bytes = align_up(pyr + 64, 256);
@@ -296,6 +309,14 @@ static int set_geometry(orbgpu_extractor *e, int w, int h)
     if ((rc = e->xtab.ensure(xt.size() * sizeof(XTab) + 16))) return rc;
     if ((rc = e->ytab.ensure(yt.size() * sizeof(YTab) + 16))) return rc;
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    // FAST cell table: level | cell row << 8 | cell column << 20
+    std::vector<uint32_t> ctab((size_t)G.total_cells);
+    for (int l = 0; l < G.nlevels; l++)
+        for (int i = 0; i < G.lv[l].nRows; i++)
+            for (int j = 0; j < G.lv[l].nCols; j++)
+                ctab[(size_t)G.lv[l].cell_off + (size_t)i * G.lv[l].nCols + j] = (uint32_t)l | ((uint32_t)i << 8) | ((uint32_t)j << 20);
+    if ((rc = e->cell_tab.ensure(ctab.size() * 4 + 16))) return rc;
+    ORBGPU_HIP_CHECK(hipMemcpy(e->cell_tab.p, ctab.data(), ctab.size() * 4, hipMemcpyHostToDevice));
     ORBGPU_HIP_CHECK(hipMemcpy(e->xtab.p, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice));
     ORBGPU_HIP_CHECK(hipMemcpy(e->ytab.p, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice));
     e->G = G;
@@ -367,7 +388,7 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e)
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DevBuf *bufs[] = {&e->pyr, &e->blur, &e->slots, &e->cell_counts, &e->cand, &e->nodes, &e->scratch, &e->sel, &e->sel_count,
-                      &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->st_img, &e->st_kps, &e->st_desc, &e->st_counts};
+                      &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->cell_tab, &e->st_img, &e->st_kps, &e->st_desc, &e->st_counts};
     for (DevBuf *b : bufs) b->release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
@@ -478,7 +499,8 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
                              (const YTab *)e->ytab.p)))
         return rc;
     STAGE_MARK(1);
-    if ((rc = launch_fast(st, nimg, (const uint8_t *)e->pyr.p, G, (uint32_t *)e->slots.p, (int32_t *)e->cell_counts.p))) return rc;
+    if ((rc = launch_fast(st, nimg, (const uint8_t *)e->pyr.p, G, (const uint32_t *)e->cell_tab.p, (uint32_t *)e->slots.p,
+                          (int32_t *)e->cell_counts.p))) return rc;
     STAGE_MARK(2);
     // fork: the blur depends on the pyramid only.  FAST keeps every SIMD busy, the
     // quadtree is latency-bound, so the blur is released after FAST to run beside the quadtree

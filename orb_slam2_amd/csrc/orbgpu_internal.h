@@ -54,10 +54,14 @@ struct Geom {
     int32_t total_kp_cap;
     int32_t iniTh, minTh;
     int32_t gauss_variant;
+    int32_t nimg;            // frames of the current launch (set by the launchers)
     int64_t pyr_frame_bytes;
     int64_t slot_frame_u32;
     int64_t cand_frame_u32;
     int64_t node_frame;
+    // per-level tables of the fields a per-lane level lookup needs (contiguous: one scalar load each)
+    int32_t t_kp_off[ORBGPU_MAX_LEVELS], t_pitch[ORBGPU_MAX_LEVELS], t_interior[ORBGPU_MAX_LEVELS], t_patch[ORBGPU_MAX_LEVELS];
+    float t_scale[ORBGPU_MAX_LEVELS];
     LevelGeom lv[ORBGPU_MAX_LEVELS];
 };
 
@@ -73,8 +77,28 @@ __host__ __device__ inline int64_t interior_off(const LevelGeom &g) { return g.p
 
 void set_error(const char *fmt, ...);
 
+// Grids are (blocks, frames).  Workgroups are dealt to the 8 XCDs round-robin in
+// linear order; for batches of 8 or more frames the (frame, block) pair is
+// derived from the linear id so that all blocks of a frame run on one XCD and
+// share its L2 (frame % 8 picks the XCD).  The frame axis of the grid is padded
+// to a multiple of 8; padding workgroups get false.  Affects speed only.
+inline int grid_frames(int nimg) { return nimg < 8 ? nimg : (nimg + 7) & ~7; }
+
 #ifdef __HIPCC__
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ bool frame_block(int nimg, int *f, int *b)
+{
+    if (nimg < 8) {
+        *f = blockIdx.y;
+        *b = blockIdx.x;
+        return true;
+    }
+    const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, j = L >> 3, q = j / gridDim.x;
+    *f = (int)(q * 8 + (L & 7));
+    *b = (int)(j - q * gridDim.x);
+    return *f < nimg;
+}
 
 // Exclusive scan over the block (blockDim.x a multiple of 64, <= 1024).
 // lds needs 33 ints.  Every thread must call it.
