@@ -161,28 +161,32 @@ constexpr int kTP = 72;  // LDS tile pitch in bytes (18 dwords: a 66 px row + up
 
 // Strength A of the best 9-long arc: max over the 16 arcs of the minimum
 // signed contrast, both polarities.  A pixel is a FAST corner at threshold t
-// iff A > t, and cv::FAST's response is then A-1.
+// iff A > t, and cv::FAST's response is then A-1.  Both polarities run in one
+// packed 16-bit min chain on (v - p, p - v).
+typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
 {
     const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * kTP + 0];   d[1] = v - c[3 * kTP + 1];   d[2] = v - c[2 * kTP + 2];   d[3] = v - c[1 * kTP + 3];
-    d[4] = v - c[0 * kTP + 3];   d[5] = v - c[-1 * kTP + 3];  d[6] = v - c[-2 * kTP + 2];  d[7] = v - c[-3 * kTP + 1];
-    d[8] = v - c[-3 * kTP + 0];  d[9] = v - c[-3 * kTP - 1];  d[10] = v - c[-2 * kTP - 2]; d[11] = v - c[-1 * kTP - 3];
-    d[12] = v - c[0 * kTP - 3];  d[13] = v - c[1 * kTP - 3];  d[14] = v - c[2 * kTP - 2];  d[15] = v - c[3 * kTP - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
+    // (v - 255, -v) + (255 - p, p) = (v - p, p - v); 65535 * p + 255 packs (255 - p, p) without a borrow
+    const short2v cv = {(short)(v - 255), (short)(-v)};
+    int p[16];
+    p[0] = c[3 * kTP + 0];   p[1] = c[3 * kTP + 1];   p[2] = c[2 * kTP + 2];   p[3] = c[1 * kTP + 3];
+    p[4] = c[0 * kTP + 3];   p[5] = c[-1 * kTP + 3];  p[6] = c[-2 * kTP + 2];  p[7] = c[-3 * kTP + 1];
+    p[8] = c[-3 * kTP + 0];  p[9] = c[-3 * kTP - 1];  p[10] = c[-2 * kTP - 2]; p[11] = c[-1 * kTP - 3];
+    p[12] = c[0 * kTP - 3];  p[13] = c[1 * kTP - 3];  p[14] = c[2 * kTP - 2];  p[15] = c[3 * kTP - 1];
+    short2v d[16], m2[16], m4[16], m8[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+    for (int k = 0; k < 16; k++) d[k] = cv + __builtin_bit_cast(short2v, (uint32_t)p[k] * 65535u + 255u);
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int best = -256;
+    for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        best = max(best, max(lo9, -hi9));
-    }
-    return best;
+    for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+    short2v best = {-256, -256};
+#pragma unroll
+    for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
+    return max((int)best.x, (int)best.y);
 }
 
 // i / d for 0 <= i < 4096, 1 <= d <= 66, with m = ceil(2^20 / d)
