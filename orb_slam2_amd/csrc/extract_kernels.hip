@@ -190,7 +190,7 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
 }
 
 // i / d for 0 <= i < 4096, 1 <= d <= 66, with m = ceil(2^20 / d)
-__device__ __forceinline__ int div_small(int i, int m) { return (int)(((unsigned)i * (unsigned)m) >> 20); }
+__device__ __forceinline__ int div_small(int i, int m) { return (int)(__umul24((unsigned)i, (unsigned)m) >> 20); }
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G, const uint32_t *__restrict__ cell_tab,
                                                     uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts)
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int mdiv = ((1 << 20) + wi - 1) / wi;
     const uint8_t *t0 = tile + ox;  // pixel (x, y) of the cell image is t0[y * kTP + x]
     for (int i = tid; i < npix; i += 256) {
-        const int y = div_small(i, mdiv), x = i - y * wi;
+        const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
         const uint8_t *c = t0 + (y + 3) * kTP + (x + 3);
         const int v = c[0], lo = v - t, hi_ = v + t;
         // any 9-long arc contains one pixel of each opposite pair (k, k+8)
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int nq = qn;
     for (int q = tid; q < nq; q += 256) {
         const int i = queue[q];
-        const int y = div_small(i, mdiv), x = i - y * wi;
+        const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
         const int A = fast_arc_strength(t0 + (y + 3) * kTP + (x + 3));
         if (A > t) score[(y + 1) * kTP + (x + 1)] = (uint8_t)(A - 1);
     }
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     // a maximum is listed as pixel index | initial-threshold flag << 12 | score << 16
     for (int q = tid; q < nq; q += 256) {
         const int i = queue[q];
-        const int y = div_small(i, mdiv), x = i - y * wi;
+        const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
         const uint8_t *s = score + (y + 1) * kTP + (x + 1);
         const int sc = s[0];
         if (sc == 0) continue;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
             const uint32_t o = maxima[j];
             pos += ((o & 0x1000u) >= need && (o & 0xFFFu) < pix) ? 1 : 0;
         }
-        const int y = div_small((int)pix, mdiv), x = (int)pix - y * wi;
+        const int y = div_small((int)pix, mdiv), x = (int)pix - (int)__umul24(y, wi);
         // keypoint coordinates relative to (16,16): sub-image x (+3 apron) + j*wCell (:1099-1100)
         if (pos < g.cell_cap) slot[pos] = pack_cand(x + 3 + ci_j * g.wCell, y + 3 + ci_i * g.hCell, (int)(e >> 16));
     }
@@ -777,11 +777,28 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
 // ---------------------------------------------------------------------------
 constexpr int kBW = 128, kBH = 32;
 constexpr int kBSrcDw = kBW / 4 + 2;  // dwords per staged source row (4 px apron on both sides)
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t w, uint32_t acc)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, w), acc, false);
+}
+
+// Horizontal 7-tap sums of the four pixels that start at byte 4 of (a, b, d): pixel j
+// needs bytes 1+j .. 7+j, taken as two 4-byte windows for two byte dot products.
+__device__ __forceinline__ void blur_row4(uint32_t a, uint32_t b, uint32_t d, uint32_t klo, uint32_t khi, uint32_t (&o)[4])
+{
+    o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d, b, 1), khi, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 1), klo, 0u, false), false);
+    o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d, b, 2), khi, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 2), klo, 0u, false), false);
+    o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d, b, 3), khi, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 3), klo, 0u, false), false);
+    o[3] = __builtin_amdgcn_udot4(d, khi, __builtin_amdgcn_udot4(b, klo, 0u, false), false);
+}
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G)
 {
     __shared__ uint32_t src[(kBH + 6) * kBSrcDw];
-    __shared__ uint16_t hrow[(kBH + 6) * kBW];
+    // horizontal sums (16 bit) of source rows 2i and 2i+1 share a dword: hpair[i][x] = h[2i][x] | h[2i+1][x] << 16
+    __shared__ __align__(16) uint32_t hpair[(kBH + 6) / 2 * kBW];
     int f, t;
     if (!frame_block(G.nimg, &f, &t)) return;
     const int tid = threadIdx.x;
@@ -795,7 +812,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const LevelGeom &g = G.lv[l];
     const int tilesX = (g.w + kBW - 1) / kBW;
     const int ty0 = (t / tilesX) * kBH, tx0 = (t % tilesX) * kBW;
-    const int k0 = 18, k1 = 34, k2 = G.gauss_variant ? 48 : 49, k3 = G.gauss_variant ? 56 : 55;
+    // taps (:1487, cv::GaussianBlur 7x7 sigma 2 in 8-bit fixed point) as byte / 16-bit dot-product operands
+    const uint32_t k0 = 18, k1 = 34, k2 = G.gauss_variant ? 48 : 49, k3 = G.gauss_variant ? 56 : 55;
+    const uint32_t klo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), khi = k2 | (k1 << 8) | (k0 << 16);
     const uint8_t *in = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
     // stage rows ty0-3 .. ty0+kBH+2, columns tx0-4 .. tx0+kBW+3 (clamped into the halo)
     const int xlim = (g.w + 15) & ~3, ylim = g.h + 2;
@@ -805,43 +824,40 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         src[i] = *reinterpret_cast<const uint32_t *>(in + (int64_t)y * g.pitch + x);
     }
     __syncthreads();
-    // horizontal pass: 4 outputs from 12 staged bytes
-    for (int i = tid; i < (kBH + 6) * (kBW / 4); i += 256) {
-        const int r = i >> 5, c = i & 31;
-        const uint32_t *sp = src + r * kBSrcDw + c;
-        const uint32_t a = sp[0], b = sp[1], d = sp[2];
-        // p[k] = pixel (4c - 4 + k) of the tile row, k = 0..11; outputs need p[1..10]
-        const int p1 = (a >> 8) & 255, p2 = (a >> 16) & 255, p3 = a >> 24;
-        const int p4 = b & 255, p5 = (b >> 8) & 255, p6 = (b >> 16) & 255, p7 = b >> 24;
-        const int p8 = d & 255, p9 = (d >> 8) & 255, p10 = (d >> 16) & 255;
-        const uint32_t o0 = k0 * (p1 + p7) + k1 * (p2 + p6) + k2 * (p3 + p5) + k3 * p4;
-        const uint32_t o1 = k0 * (p2 + p8) + k1 * (p3 + p7) + k2 * (p4 + p6) + k3 * p5;
-        const uint32_t o2 = k0 * (p3 + p9) + k1 * (p4 + p8) + k2 * (p5 + p7) + k3 * p6;
-        const uint32_t o3 = k0 * (p4 + p10) + k1 * (p5 + p9) + k2 * (p6 + p8) + k3 * p7;
-        *reinterpret_cast<uint2 *>(hrow + r * kBW + 4 * c) = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));
+    // horizontal pass: a thread takes two source rows x four columns and writes four packed dwords
+    for (int i = tid; i < (kBH + 6) / 2 * (kBW / 4); i += 256) {
+        const int rp = i >> 5, c = i & 31;
+        const uint32_t *sp = src + 2 * rp * kBSrcDw + c;
+        uint32_t e[4], o[4];
+        blur_row4(sp[0], sp[1], sp[2], klo, khi, e);
+        blur_row4(sp[kBSrcDw], sp[kBSrcDw + 1], sp[kBSrcDw + 2], klo, khi, o);
+        *reinterpret_cast<uint4 *>(hpair + rp * kBW + 4 * c) = make_uint4(e[0] | (o[0] << 16), e[1] | (o[1] << 16), e[2] | (o[2] << 16), e[3] | (o[3] << 16));
     }
     __syncthreads();
-    // vertical pass: thread = 4 columns x 4 rows
+    // vertical pass: thread = 4 columns x 4 rows; output row y0+rr sums source rows y0+rr .. y0+rr+6,
+    // i.e. four row pairs with the taps aligned for an even or an odd first row
     const int c = tid & 31, rg = tid >> 5;
     const int x = tx0 + 4 * c;
     uint8_t *out = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
-    uint2 h[10];
+    const uint32_t we0 = k0 | (k1 << 16), we1 = k2 | (k3 << 16), we2 = k2 | (k1 << 16), we3 = k0;
+    const uint32_t wo0 = k0 << 16, wo1 = k1 | (k2 << 16), wo2 = k3 | (k2 << 16), wo3 = k1 | (k0 << 16);
+    uint4 h[5];
 #pragma unroll
-    for (int k = 0; k < 10; k++) h[k] = *reinterpret_cast<const uint2 *>(hrow + (rg * 4 + k) * kBW + 4 * c);
+    for (int k = 0; k < 5; k++) h[k] = *reinterpret_cast<const uint4 *>(hpair + (rg * 2 + k) * kBW + 4 * c);
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
-        const int y = ty0 + rg * 4 + rr;
+        const int y = ty0 + rg * 4 + rr, b = rr >> 1;
         uint32_t packed = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            int v[7];
-#pragma unroll
-            for (int k = 0; k < 7; k++) {
-                const uint32_t wv = (q < 2) ? h[rr + k].x : h[rr + k].y;
-                v[k] = (q & 1) ? (int)(wv >> 16) : (int)(wv & 0xFFFF);
-            }
-            const int s = k0 * (v[0] + v[6]) + k1 * (v[1] + v[5]) + k2 * (v[2] + v[4]) + k3 * v[3];
-            packed |= (uint32_t)min((s + 32768) >> 16, 255) << (8 * q);
+            const uint32_t p0 = q == 0 ? h[b].x : q == 1 ? h[b].y : q == 2 ? h[b].z : h[b].w;
+            const uint32_t p1 = q == 0 ? h[b + 1].x : q == 1 ? h[b + 1].y : q == 2 ? h[b + 1].z : h[b + 1].w;
+            const uint32_t p2 = q == 0 ? h[b + 2].x : q == 1 ? h[b + 2].y : q == 2 ? h[b + 2].z : h[b + 2].w;
+            const uint32_t p3 = q == 0 ? h[b + 3].x : q == 1 ? h[b + 3].y : q == 2 ? h[b + 3].z : h[b + 3].w;
+            uint32_t sacc;
+            if (rr & 1) sacc = dot2_u16(p3, wo3, dot2_u16(p2, wo2, dot2_u16(p1, wo1, dot2_u16(p0, wo0, 32768u))));
+            else sacc = dot2_u16(p3, we3, dot2_u16(p2, we2, dot2_u16(p1, we1, dot2_u16(p0, we0, 32768u))));
+            packed |= min(sacc >> 16, 255u) << (8 * q);
         }
         // a partial last group spills at most 3 bytes into the unused margin of the blurred plane
         if (x < g.w && y < g.h) *reinterpret_cast<uint32_t *>(out + (int64_t)y * g.pitch + x) = packed;
