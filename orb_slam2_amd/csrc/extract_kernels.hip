@@ -66,15 +66,17 @@ __global__ __launch_bounds__(256) void k_halo_sides(uint8_t *__restrict__ pyr, G
 }
 
 // Level 0 = the input image; 16 pixels per thread, 128-bit accesses when the
-// source row is 16-byte aligned.
+// source row is 16-byte aligned.  Threads are numbered over (row, 16-pixel group).
 __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ img, int stride, size_t frame_stride,
                                                    uint8_t *__restrict__ pyr, Geom G)
 {
     const LevelGeom &g = G.lv[0];
     int f, b;
     if (!frame_block(G.nimg, &f, &b)) return;
-    const int y = b % g.h, x = ((b / g.h) * 256 + threadIdx.x) * 16;
-    if (x >= g.w) return;
+    const int groups = (g.w + 15) >> 4;
+    const int t = b * 256 + threadIdx.x;
+    const int y = t / groups, x = (t - y * groups) * 16;
+    if (y >= g.h) return;
     const uint8_t *src = img + (size_t)f * frame_stride + (size_t)y * stride + x;
     const int n = min(16, g.w - x);
     uint32_t v[4] = {0, 0, 0, 0};
@@ -1127,7 +1129,7 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     Geom G = G_;
     G.nimg = nimg;
     const LevelGeom &g0 = G.lv[0];
-    hipLaunchKernelGGL(k_pyr_copy0, dim3(((g0.w + 4095) / 4096) * g0.h, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G_);
+    hipLaunchKernelGGL(k_pyr_copy0, dim3((((g0.w + 15) / 16) * g0.h + 255) / 256, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G_);
     int rows = (g0.h + 2 * kEdge + 15) / 16;
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
