@@ -529,24 +529,23 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, in
     *out_expand = nexp;
 }
 
-__global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restrict__ slots,
-                                                 const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,
-                                                 int32_t *scratch, uint32_t *__restrict__ sel,
-                                                 int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,
-                                                 int32_t *__restrict__ status, int keys_cap, int lds_nodes)
+__device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__restrict__ slots,
+                                             const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,
+                                             int32_t *scratch, uint32_t *__restrict__ sel,
+                                             int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,
+                                             int32_t *__restrict__ status, int keys_cap, int lds_nodes, int dyn_coff_off)
 {
     // dynamic LDS: keys_cap 64-bit sort keys, then (lds_nodes != 0) the node
     // arrays and per-node work lists of this level -- keeping them on chip takes
     // a dozen dependent global-memory round trips out of every subdivision round
     extern __shared__ __align__(16) unsigned char dyn_lds[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(dyn_lds);
+    int *coff = reinterpret_cast<int *>(dyn_lds + dyn_coff_off);  // blockDim.x + 1 cell offsets of the gather
     __shared__ int scan_lds[33];
     __shared__ int root_cnt[kMaxRoots], root_start[kMaxRoots];
     __shared__ int sh_a, lds4[4];
-    __shared__ int coff[1025];
 
     const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-    const int lane = lane_id(), wid = tid >> 6, nw = nt >> 6;
     const LevelGeom &g = G.lv[level];
     const int N = g.quota;
     OctCtx c;
@@ -769,6 +768,22 @@ __global__ __launch_bounds__(1024) void k_octree(Geom G, const uint32_t *__restr
     }
     if (tid == 0) *out_count = size;
 }
+
+#define OCTREE_ARGS                                                                                                          \
+    Geom G, const uint32_t *__restrict__ slots, const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,       \
+        int32_t *scratch, uint32_t *__restrict__ sel, int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,     \
+        int32_t *__restrict__ status, int keys_cap, int lds_nodes, int dyn_coff_off
+// one frame: a few 1024-thread workgroups
+__global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
+{
+    octree_level(G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, dyn_coff_off);
+}
+// a batch: 256-thread workgroups, registers capped so that eight of them share a CU
+__global__ __launch_bounds__(256, 8) void k_octree_batch(OCTREE_ARGS)
+{
+    octree_level(G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, dyn_coff_off);
+}
+#undef OCTREE_ARGS
 
 // ---------------------------------------------------------------------------
 // GaussianBlur 7x7, sigma 2, 8-bit fixed point (called at :1502).  All levels
@@ -1159,11 +1174,16 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     while (keys_cap < maxcap) keys_cap <<= 1;
     const size_t node_bytes = (size_t)maxcap * (2 * sizeof(QNode) + 8 * sizeof(int32_t));
     const int lds_nodes = (size_t)keys_cap * 8 + node_bytes <= 56 * 1024;
-    const size_t dyn = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
     // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several
     const int threads = nimg * G.nlevels >= 256 ? 256 : 1024;
-    hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch, sel,
-                       sel_count, cand_count, status, keys_cap, lds_nodes);
+    const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
+    const size_t dyn = coff_off + (size_t)(threads + 1) * 4;
+    if (threads == 256)
+        hipLaunchKernelGGL(k_octree_batch, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch,
+                           sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off);
+    else
+        hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch, sel,
+                           sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
