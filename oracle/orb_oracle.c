@@ -1083,7 +1083,9 @@ int orc_search_by_projection(int mode, const orc_wquery *q, const uint8_t *qdesc
                 bestDist2 = dist;
             }
         }
-        if (bestDist <= th_dist) {
+        /* bestIdx < 0: every candidate was skipped; the reference never gets here with one (its
+         * thresholds are below the initial 256), a caller-supplied th_dist >= 256 must not either */
+        if (bestIdx >= 0 && bestDist <= th_dist) {
             if (mode == 0 && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)
                 continue;
             assign[bestIdx] = i;

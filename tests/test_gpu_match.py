@@ -111,6 +111,23 @@ def test_search_by_projection_heavy_conflicts(matcher, oracle, frames):
         assert n == rn and np.array_equal(assign, rassign)
 
 
+@pytest.mark.parametrize("r,nq", [(60.0, 301), (25.0, 999), (110.0, 77)])
+def test_search_by_projection_cache_overflow(matcher, oracle, frames, r, nq):
+    """Windows of at most 32 grid columns (two queries share a wave) in which every candidate passes
+    th_dist = 256, so the 16-entry candidate caches overflow; an odd query count leaves half a wave idle."""
+    from orb_slam2_amd import api
+    (k1, d1), (k2, d2) = frames[0], frames[1]
+    q = np.zeros(nq, api.WQUERY_DTYPE)
+    q["u"] = k1["x"][:nq] - 2.0; q["v"] = k1["y"][:nq] - 1.0; q["r"] = r; q["minLevel"] = -1; q["maxLevel"] = -1
+    q["angle"] = k1["angle"][:nq]; q["ur"] = -1; q["flags"] = 3
+    for mode in (0, 1):
+        n, assign = matcher.SearchByProjection(mode, q, d1[:nq], k2, d2, _bounds(), th_dist=256)
+        rn, rassign = oracle.search_by_projection(mode, q.view(oracle.WQUERY_DTYPE), d1[:nq], k2.view(oracle.KEYPOINT_DTYPE),
+                                                  d2, _bounds(), th_dist=256, nnratio=matcher.mfNNratio, checkOri=True)
+        assert n == rn and np.array_equal(assign, rassign)
+        assert n > nq // 4
+
+
 @pytest.mark.parametrize("window,ratio,ori", [(100, 0.9, True), (30, 0.7, False), (500, 0.95, True)])
 def test_search_for_initialization(oracle, frames, window, ratio, ori):
     from orb_slam2_amd.api import ORBmatcher
