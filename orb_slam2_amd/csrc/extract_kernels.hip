@@ -203,9 +203,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     __shared__ uint32_t maxima[(kMaxTile - 5) * (kMaxTile - 5) / 4];  // strict 3x3 maxima are never adjacent
     __shared__ int qn, nmax, nini;
 
-    int f, cell;
-    if (!frame_block(G.nimg, &f, &cell)) return;
-    const int tid = threadIdx.x;
+    // Workgroups are dealt to the 8 XCDs round-robin.  Within every run of 32 cells, workgroups
+    // b, b+8, b+16, b+24 (one XCD) take four consecutive cells: horizontal neighbours read the
+    // same 128-byte lines of the pyramid, so they should meet in one L2.
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int cell = (b & ~31) + ((b & 7) << 2) + ((b >> 3) & 3);
+    if (cell >= G.total_cells) return;
     // cell_tab: level | cell row << 8 | cell column << 20
     const uint32_t ct = cell_tab[cell];
     const int l = ct & 0xFF, ci_i = (ct >> 8) & 0xFFF, ci_j = ct >> 20;
@@ -1160,7 +1164,7 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
 int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
                 int32_t *cell_counts)
 {
-    hipLaunchKernelGGL(k_fast_cells, dim3(G.total_cells, nimg), dim3(256), 0, st, pyr, G, cell_tab, slots, cell_counts);
+    hipLaunchKernelGGL(k_fast_cells, dim3((G.total_cells + 31) & ~31, nimg), dim3(256), 0, st, pyr, G, cell_tab, slots, cell_counts);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
