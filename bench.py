@@ -215,7 +215,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if pm.get("batch") == Bs:
-                kk = pm["kernels"][{"pyramid": "k_pyr_resize", "fast_cells": "k_fast_cells", "octree": "k_octree", "blur": "k_blur",
+                kk = pm["kernels"][{"pyramid": "k_pyr_resize", "fast_cells": "k_fast_cells", "octree": "k_octree_batch", "blur": "k_blur",
                                     "describe": "k_describe"}[dom_name]]
                 traffic = (kk["FETCH_SIZE_KB_per_launch"] * kk.get("fetch_corr", 1.0) + kk["WRITE_SIZE_KB_per_launch"]) * 1024
         except Exception:
@@ -240,7 +240,9 @@ def main():
                        "parallelism": "frames sharded across %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": float(stage_ms[dom])},
+                         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": float(stage_ms[dom]),
+                         "note": "integer byte kernels: the binding limit is vector-ALU issue (1 wave-instr / 4 cycles / SIMD), "
+                                 "see profiles/r01_sq_counters.txt; traffic = committed rocprofv3 PMC passes of this workload"},
             "stages_ms_per_step": dict({n: float(v) for n, v in zip(names, stage_ms)}, match=match_ms),
             "extract_algorithmic_GBps": frame_alg * Bs / (float(stage_ms.sum()) * 1e-3) / 1e9,
             "gpu_ms_per_step": gpu_ms / args.steps,
