@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
 // One workgroup per (cell, frame).  Output: per-cell ordered list of packed
 // candidates in a fixed-capacity slot + the count.
 // ---------------------------------------------------------------------------
+constexpr int kFastThreads = 128;  // threads of a FAST workgroup (one cell)
 constexpr int kTP = 72;  // LDS tile pitch in bytes (18 dwords: a 66 px row + up to 3 bytes of alignment slack)
 
 // Strength A of the best 9-long arc: max over the 16 arcs of the minimum
@@ -194,13 +195,17 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
 // i / d for 0 <= i < 4096, 1 <= d <= 66, with m = ceil(2^20 / d)
 __device__ __forceinline__ int div_small(int i, int m) { return (int)(__umul24((unsigned)i, (unsigned)m) >> 20); }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G, const uint32_t *__restrict__ cell_tab,
-                                                    uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts)
+__global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G, const uint32_t *__restrict__ cell_tab,
+                                                    uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts,
+                                                    int lds_score_off, int lds_maxima_off, int lds_queue_off)
 {
-    __shared__ __align__(16) uint8_t tile[kMaxTile * kTP];
-    __shared__ __align__(16) uint8_t score[(kMaxTile - 4) * kTP];  // interior + 1 px zero border
-    __shared__ uint16_t queue[(kMaxTile - 6) * (kMaxTile - 6)];
-    __shared__ uint32_t maxima[(kMaxTile - 5) * (kMaxTile - 5) / 4];  // strict 3x3 maxima are never adjacent
+    // dynamic LDS, sized by the launcher for the largest cell of the geometry:
+    // tile | score (interior + 1 px zero border) | maxima | queue
+    extern __shared__ __align__(16) uint8_t fast_lds[];
+    uint8_t *tile = fast_lds;
+    uint8_t *score = tile + lds_score_off;
+    uint32_t *maxima = reinterpret_cast<uint32_t *>(tile + lds_maxima_off);  // strict 3x3 maxima are never adjacent
+    uint16_t *queue = reinterpret_cast<uint16_t *>(tile + lds_queue_off);
     __shared__ int qn, nmax, nini;
 
     // Workgroups are dealt to the 8 XCDs round-robin.  Within every run of 32 cells, workgroups
@@ -237,10 +242,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     {
         const int c = tid & 31, r0 = tid >> 5;
         if (c < ndw)
-            for (int r = r0; r < ch; r += 8)
+            for (int r = r0; r < ch; r += kFastThreads / 32)
                 reinterpret_cast<uint32_t *>(tile)[r * (kTP / 4) + c] = *reinterpret_cast<const uint32_t *>(src + (int64_t)r * g.pitch + 4 * c);
     }
-    for (int i = tid; i < ((hi + 2) * (kTP / 4) + 3) / 4; i += 256) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < ((hi + 2) * (kTP / 4) + 3) / 4; i += kFastThreads) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) { qn = 0; nmax = 0; nini = 0; }
     __syncthreads();
 
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int npix = wi * hi;
     const int mdiv = ((1 << 20) + wi - 1) / wi;
     const uint8_t *t0 = tile + ox;  // pixel (x, y) of the cell image is t0[y * kTP + x]
-    for (int i = tid; i < npix; i += 256) {
+    for (int i = tid; i < npix; i += kFastThreads) {
         const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
         const uint8_t *c = t0 + (y + 3) * kTP + (x + 3);
         const int v = c[0], lo = v - t, hi_ = v + t;
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     }
     __syncthreads();
     const int nq = qn;
-    for (int q = tid; q < nq; q += 256) {
+    for (int q = tid; q < nq; q += kFastThreads) {
         const int i = queue[q];
         const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
         const int A = fast_arc_strength(t0 + (y + 3) * kTP + (x + 3));
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     __syncthreads();
     // stage 2: strict 3x3 maximum inside the cell, evaluated for the corners only;
     // a maximum is listed as pixel index | initial-threshold flag << 12 | score << 16
-    for (int q = tid; q < nq; q += 256) {
+    for (int q = tid; q < nq; q += kFastThreads) {
         const int i = queue[q];
         const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
         const uint8_t *s = score + (y + 1) * kTP + (x + 1);
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int n = nmax, use_ini = nini > 0;
     const int count = use_ini ? nini : n;
     uint32_t *slot = slots + (int64_t)f * G.slot_frame_u32 + g.slot_off + (int64_t)ci * g.cell_cap;
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += kFastThreads) {
         const uint32_t e = maxima[k];
         if (use_ini && !(e & 0x1000u)) continue;
         const uint32_t need = use_ini ? 0x1000u : 0u, pix = e & 0xFFFu;
@@ -1164,7 +1169,17 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
 int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
                 int32_t *cell_counts)
 {
-    hipLaunchKernelGGL(k_fast_cells, dim3((G.total_cells + 31) & ~31, nimg), dim3(256), 0, st, pyr, G, cell_tab, slots, cell_counts);
+    // LDS regions for the largest cell: rows of kTP bytes (all offsets multiples of 16)
+    int wmax = 0, hmax = 0;
+    for (int l = 0; l < G.nlevels; l++) {
+        wmax = G.lv[l].wCell > wmax ? G.lv[l].wCell : wmax;
+        hmax = G.lv[l].hCell > hmax ? G.lv[l].hCell : hmax;
+    }
+    const int score_off = (hmax + 6) * kTP, maxima_off = score_off + (((hmax + 2) * kTP + 15) & ~15);
+    const int queue_off = maxima_off + ((((wmax + 1) / 2) * ((hmax + 1) / 2) * 4 + 15) & ~15);
+    const size_t lds = (size_t)queue_off + (size_t)wmax * hmax * 2;
+    hipLaunchKernelGGL(k_fast_cells, dim3((G.total_cells + 31) & ~31, nimg), dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots, cell_counts,
+                       score_off, maxima_off, queue_off);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
