@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the ORB front-end path (extract + windowed match) on MI355X.
 
-One "step" = one batch of B synthetic TUM-like frames (640x480, 1000 features,
+One "step" = one batch of B (default 2048) synthetic TUM-like frames (640x480, 1000 features,
 8 levels, scale 1.2, FAST 20/7), already resident in HBM: extract all B frames,
 then SearchByProjection(Cur, Last)-style windowed matching of every frame
 against its predecessor (the predecessor of frame 0 is the last frame of the
@@ -66,8 +66,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--streams", type=int, default=1, help="independent sub-pipelines (HIP streams) the batch is split over")
+    ap.add_argument("--batch", type=int, default=2048, help="frames per step and GPU")
+    ap.add_argument("--streams", type=int, default=4, help="independent sub-pipelines (HIP streams) the batch is split over")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency probe (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()

@@ -94,8 +94,7 @@ __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ i
 // cv::resize INTER_LINEAR 8UC1 fixed-point arithmetic (called at :1550) from
 // level l-1 into level l.  A workgroup produces a kRW x kRH output tile: the
 // source window of the tile is staged in LDS with coalesced 32-bit loads, then a
-// thread produces a 4 x 4 block of output pixels from LDS bytes (tap tables
-// amortised over four rows, one 32-bit store per row).
+// thread produces a 2 x 8 block of output pixels from LDS bytes.
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, Geom G, int level,
                                                     const XTab *__restrict__ xtab, const YTab *__restrict__ ytab)
 {
@@ -123,33 +122,59 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
         rs_src[r * P + c] = *reinterpret_cast<const uint32_t *>(S + (int64_t)r * gs.pitch + 4 * c);
     }
     __syncthreads();
-    const int dx0 = tx0 + 4 * (tid & 31), dy0 = ty0 + 4 * (tid >> 5);
-    if (dx0 >= gd.w || dy0 >= gd.h) return;
-    int xo[4], a0[4], a1[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const XTab t = xt[min(dx0 + k, gd.w - 1)];
-        xo[k] = t.sx - sx_al;  // the right tap is the next byte: its weight is 0 where the reference clamps it
-        a0[k] = t.a0;
-        a1[k] = t.a1;
-    }
+    // A wave produces 8 output rows x 128 columns, a lane 2 columns of each row.  The rows are uniform
+    // over the wave, so the vertical tap table is scalar data and the horizontal sums of a source row,
+    // shared by consecutive output rows, are computed once and kept (rows A and B below).
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dx0 = tx0 + 2 * (tid & 63), dy0 = ty0 + 8 * wv;
+    if (dy0 >= gd.h) return;
+    const XTab t0 = xt[min(dx0, gd.w - 1)], t1 = xt[min(dx0 + 1, gd.w - 1)];
+    // the right tap is the next byte: its weight is 0 where the reference clamps it
+    const int xo0 = t0.sx - sx_al, xo1 = t1.sx - sx_al;
+    int xr0 = xo0 + 1, xr1 = xo1 + 1;  // kept opaque: two byte reads, not one 16-bit read at an odd LDS address
+    asm("" : "+v"(xr0), "+v"(xr1));
+    const int a00 = t0.a0, a01 = t0.a1, a10 = t1.a0, a11 = t1.a1;
     const uint8_t *L = reinterpret_cast<const uint8_t *>(rs_src);
-    const int n = min(4, gd.w - dx0);
+    uint8_t *D = base + interior_off(gd) + dx0;  // this lane's column in row 0
+    const int n = gd.w - dx0;  // columns of this lane inside the level: <= 0 none, 1 the first only
+    int idA = -1, idB = -1, hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0;
+    YTab ytv[8];  // all eight (uniform) loads in flight at once
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if (dy0 + r >= gd.h) break;
-        const YTab y = yt[dy0 + r];
-        const uint8_t *R0 = L + (y.sy0 - sy_min) * P * 4, *R1 = L + (y.sy1 - sy_min) * P * 4;
-        uint32_t v = 0;
+    for (int r = 0; r < 8; r++) ytv[r] = yt[min(dy0 + r, gd.h - 1)];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int r0 = R0[xo[k]] * a0[k] + R0[xo[k] + 1] * a1[k];
-            const int r1 = R1[xo[k]] * a0[k] + R1[xo[k] + 1] * a1[k];
-            const int px = (((y.b0 * (r0 >> 4)) >> 16) + ((y.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            v |= (uint32_t)px << (8 * k);
+    for (int r = 0; r < 8; r++) {
+        const int y = dy0 + r;
+        if (y >= gd.h) break;
+        const YTab yv = ytv[r];
+        if (yv.sy0 == idB) {
+            hA0 = hB0; hA1 = hB1; idA = idB;
+        } else if (yv.sy0 != idA) {
+            const uint8_t *R = L + (yv.sy0 - sy_min) * P * 4;
+            hA0 = (R[xo0] * a00 + R[xr0] * a01) >> 4;
+            hA1 = (R[xo1] * a10 + R[xr1] * a11) >> 4;
+            idA = yv.sy0;
         }
-        const uint32_t vv[1] = {v};
-        store_span_with_halo<1>(base + interior_off(gd), gd.pitch, gd.w, gd.h, dx0, dy0 + r, n, vv);
+        if (yv.sy1 == idA) {
+            hB0 = hA0; hB1 = hA1; idB = idA;
+        } else if (yv.sy1 != idB) {
+            const uint8_t *R = L + (yv.sy1 - sy_min) * P * 4;
+            hB0 = (R[xo0] * a00 + R[xr0] * a01) >> 4;
+            hB1 = (R[xo1] * a10 + R[xr1] * a11) >> 4;
+            idB = yv.sy1;
+        }
+        const int p0 = (((yv.b0 * hA0) >> 16) + ((yv.b1 * hB0) >> 16) + 2) >> 2;
+        const int p1 = (((yv.b0 * hA1) >> 16) + ((yv.b1 * hB1) >> 16) + 2) >> 2;
+        // the row and, for rows next to the top / bottom edge, its reflect-101 image in the halo
+        const int ym = (y >= 1 && y <= kEdge) ? -y : ((y >= gd.h - 1 - kEdge && y <= gd.h - 2) ? 2 * (gd.h - 1) - y : y);
+        uint8_t *q = D + y * gd.pitch, *qm = D + ym * gd.pitch;  // 32-bit scalar row offsets (a frame's pyramid is < 2 GiB)
+        if (n >= 2) {
+            const uint16_t v = (uint16_t)(p0 | (p1 << 8));
+            *reinterpret_cast<uint16_t *>(q) = v;
+            if (ym != y) *reinterpret_cast<uint16_t *>(qm) = v;
+        } else if (n == 1) {
+            *q = (uint8_t)p0;
+            if (ym != y) *qm = (uint8_t)p0;
+        }
     }
 }
 
