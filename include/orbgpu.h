@@ -83,7 +83,10 @@ int orbgpu_extractor_sync(orbgpu_extractor *e);
  * call records HIP events between its stages on the handle's stream;
  * orbgpu_extractor_stage_times synchronises and returns the mean milliseconds
  * of {pyramid, FAST cells, quadtree, blur, describe} over the calls since
- * profiling was enabled (at most the last 128). */
+ * profiling was enabled (at most the last 128).  enable = 1 times the normal
+ * schedule (the blur runs on a side stream beside the quadtree, so those two
+ * intervals overlap); enable = 2 keeps the blur on the main stream so that
+ * every stage is timed alone; 0 switches timing off. */
 int orbgpu_extractor_profile(orbgpu_extractor *e, int32_t enable);
 int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms5, int32_t *ncalls);
 

@@ -827,7 +827,6 @@ __global__ __launch_bounds__(256, 8) void k_octree_batch(OCTREE_ARGS)
 // LDS accesses for the 16-bit row sums).
 // ---------------------------------------------------------------------------
 constexpr int kBW = 128, kBH = 32;
-constexpr int kBSrcDw = kBW / 4 + 2;  // dwords per staged source row (4 px apron on both sides)
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t w, uint32_t acc)
@@ -847,7 +846,6 @@ __device__ __forceinline__ void blur_row4(uint32_t a, uint32_t b, uint32_t d, ui
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G)
 {
-    __shared__ uint32_t src[(kBH + 6) * kBSrcDw];
     // horizontal sums (16 bit) of source rows 2i and 2i+1 share a dword: hpair[i][x] = h[2i][x] | h[2i+1][x] << 16
     __shared__ __align__(16) uint32_t hpair[(kBH + 6) / 2 * kBW];
     int f, t;
@@ -867,21 +865,20 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const uint32_t k0 = 18, k1 = 34, k2 = G.gauss_variant ? 48 : 49, k3 = G.gauss_variant ? 56 : 55;
     const uint32_t klo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), khi = k2 | (k1 << 8) | (k0 << 16);
     const uint8_t *in = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
-    // stage rows ty0-3 .. ty0+kBH+2, columns tx0-4 .. tx0+kBW+3 (clamped into the halo)
+    // horizontal pass straight from global memory (rows ty0-3 .. ty0+kBH+2, clamped into the halo):
+    // a thread takes two source rows x four columns (three aligned dwords per row: neighbours'
+    // loads overlap in L1) and writes four packed dwords
     const int xlim = (g.w + 15) & ~3, ylim = g.h + 2;
-    for (int i = tid; i < (kBH + 6) * kBSrcDw; i += 256) {
-        const int r = i / kBSrcDw, c = i - r * kBSrcDw;
-        const int y = min(ty0 + r - 3, ylim), x = min(tx0 - 4 + 4 * c, xlim);
-        src[i] = *reinterpret_cast<const uint32_t *>(in + (int64_t)y * g.pitch + x);
-    }
-    __syncthreads();
-    // horizontal pass: a thread takes two source rows x four columns and writes four packed dwords
     for (int i = tid; i < (kBH + 6) / 2 * (kBW / 4); i += 256) {
         const int rp = i >> 5, c = i & 31;
-        const uint32_t *sp = src + 2 * rp * kBSrcDw + c;
+        const int y0 = min(ty0 + 2 * rp - 3, ylim), y1 = min(ty0 + 2 * rp - 2, ylim);
+        const int xa = min(tx0 - 4 + 4 * c, xlim), xb = min(tx0 + 4 * c, xlim), xd = min(tx0 + 4 + 4 * c, xlim);
+        const uint8_t *r0 = in + (int64_t)y0 * g.pitch, *r1 = in + (int64_t)y1 * g.pitch;
         uint32_t e[4], o[4];
-        blur_row4(sp[0], sp[1], sp[2], klo, khi, e);
-        blur_row4(sp[kBSrcDw], sp[kBSrcDw + 1], sp[kBSrcDw + 2], klo, khi, o);
+        blur_row4(*reinterpret_cast<const uint32_t *>(r0 + xa), *reinterpret_cast<const uint32_t *>(r0 + xb),
+                  *reinterpret_cast<const uint32_t *>(r0 + xd), klo, khi, e);
+        blur_row4(*reinterpret_cast<const uint32_t *>(r1 + xa), *reinterpret_cast<const uint32_t *>(r1 + xb),
+                  *reinterpret_cast<const uint32_t *>(r1 + xd), klo, khi, o);
         *reinterpret_cast<uint4 *>(hpair + rp * kBW + 4 * c) = make_uint4(e[0] | (o[0] << 16), e[1] | (o[1] << 16), e[2] | (o[2] << 16), e[3] | (o[3] << 16));
     }
     __syncthreads();

@@ -84,6 +84,7 @@ struct orbgpu_extractor {
     size_t h_pinned_bytes = 0;
     // optional stage timing: a ring of event sets, one set per extract call
     bool profile = false;
+    bool serialize = false;  // profiling mode 2: the blur stays on the main stream so every stage is timed alone
     std::vector<hipEvent_t> ev;  // kProfSets * kProfEvents
     int prof_next = 0, prof_used = 0;
 };
@@ -422,6 +423,7 @@ int orbgpu_extractor_profile(orbgpu_extractor *e, int32_t enable)
         for (auto &x : e->ev) ORBGPU_HIP_CHECK(hipEventCreate(&x));
     }
     e->profile = enable != 0;
+    e->serialize = enable == 2;
     e->prof_next = 0;
     e->prof_used = 0;
     return ORBGPU_OK;
@@ -433,7 +435,8 @@ int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms5, int32_t *ncall
     ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
     // {pyramid, fast, octree, blur (aux stream), describe (includes waiting for the blur)}
-    static const int from[5] = {0, 1, 2, 5, 3}, to[5] = {1, 2, 3, 6, 4};
+    // serialized mode: the blur sits between FAST and the quadtree on the one stream
+    const int from[5] = {0, 1, e->serialize ? 6 : 2, 5, 3}, to[5] = {1, 2, 3, 6, 4};
     for (int i = 0; i < 5; i++) ms5[i] = 0.f;
     for (int s = 0; s < e->prof_used; s++)
         for (int i = 0; i < 5; i++) {
@@ -504,19 +507,21 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
     STAGE_MARK(2);
     // fork: the blur depends on the pyramid only.  FAST keeps every SIMD busy, the
     // quadtree is latency-bound, so the blur is released after FAST to run beside the quadtree
-    hipStream_t ax = e->aux_stream;
-    ORBGPU_HIP_CHECK(hipEventRecord(e->ev_fork, st));
-    ORBGPU_HIP_CHECK(hipStreamWaitEvent(ax, e->ev_fork, 0));
+    hipStream_t ax = e->serialize ? st : e->aux_stream;
+    if (!e->serialize) {
+        ORBGPU_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+        ORBGPU_HIP_CHECK(hipStreamWaitEvent(ax, e->ev_fork, 0));
+    }
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], ax));
     if ((rc = launch_blur(ax, nimg, (const uint8_t *)e->pyr.p, (uint8_t *)e->blur.p, G))) return rc;
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
-    ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
+    if (!e->serialize) ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
     if ((rc = launch_octree(st, nimg, G, (const uint32_t *)e->slots.p, (const int32_t *)e->cell_counts.p, (uint32_t *)e->cand.p,
                             (QNode *)e->nodes.p, (int32_t *)e->scratch.p, (uint32_t *)e->sel.p, (int32_t *)e->sel_count.p,
                             (int32_t *)e->cand_count.p, (int32_t *)e->status.p)))
         return rc;
     STAGE_MARK(3);
-    ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
+    if (!e->serialize) ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
     if ((rc = launch_describe(st, nimg, (const uint8_t *)e->pyr.p, (const uint8_t *)e->blur.p, G, (const uint32_t *)e->sel.p,
                               (const int32_t *)e->sel_count.p, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts,
                               capacity, (int32_t *)e->status.p)))
