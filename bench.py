@@ -216,7 +216,8 @@ def main():
         names = ["pyramid", "fast_cells", "octree", "blur", "describe"]
         # the blur runs on a side stream beside the quadtree: main-stream time = everything but the blur
         match_ms = gpu_ms / args.steps - float(stage_ms.sum() - stage_ms[3]) if S == 1 else None
-        dom = int(np.argmax(iso_ms))  # dominant stage by its isolated launch time
+        # dominant kernel = the single-launch stage with the longest isolated time (the pyramid stage is a chain of nine launches)
+        dom = 1 + int(np.argmax(iso_ms[1:]))
         dom_name = names[dom]
         # the quadtree moves O(N) bytes; price it (if dominant) by the candidate bytes it gathers
         dom_bytes = alg[dom_name] * Bs if alg[dom_name] else 4 * 4000 * Bs

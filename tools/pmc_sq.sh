@@ -1,11 +1,12 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): one rocprofv3 PMC pass of SQ instruction counters over a
-# short bench.py run; prints per-kernel wave-instruction counts per launch.
+# short bench.py run (one stream, 512 frames per launch: per-dispatch counters need kernels that
+# do not overlap); prints per-kernel wave-instruction counts per launch.
 # usage: bash tools/pmc_sq.sh <tag>
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_sq_$tag
-timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-latency > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out -- python3 bench.py --batch 512 --streams 1 --steps 2 --warmup 1 --cpu-frames 0 --no-latency > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
 python3 - $out <<'PY'
 import collections, csv, glob, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
