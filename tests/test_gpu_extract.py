@@ -102,6 +102,23 @@ def test_batch_equals_single(oracle):
     assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
 
 
+def test_batch_of_ten_and_profiling_modes(oracle):
+    """Batches of 8 or more frames use the XCD-pinned block mapping (frame axis padded to a multiple
+    of 8); the stage-timing modes change the schedule (blur on the side stream or not), never the result."""
+    seq = synth.sequence(640, 480, 10, seed=33)
+    ex = _mk(640, 480, 1000, max_batch=10)
+    ref = [ex(seq[i]) for i in range(10)]
+    for mode in (0, 1, 2):
+        ex.profile(mode)
+        res = ex.extract_batch(seq)
+        for i in range(10):
+            assert np.array_equal(res[i][0], ref[i][0]) and np.array_equal(res[i][1], ref[i][1])
+        if mode:
+            ms, n = ex.stage_times()
+            assert n == 1 and len(ms) == 5 and (np.asarray(ms) > 0).all()
+    ex.profile(0)
+
+
 def test_degenerate_images(oracle):
     ex = _mk(640, 480, 1000)
     k, d = ex(np.zeros((0, 0), np.uint8))
