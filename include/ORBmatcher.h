@@ -14,6 +14,7 @@
 #ifndef ORBGPU_ORBMATCHER_H
 #define ORBGPU_ORBMATCHER_H
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,61 @@ public:
                                               hasMapPoint ? hasMapPoint->data() : nullptr, assign.data(), thDist, mfNNratio,
                                               mbCheckOrientation ? 1 : 0, &nmatches)))
             return 0;
+        return nmatches;
+    }
+
+    // SearchByBoW(KeyFrame *pKF, Frame &F, vpMapPointMatches)            strict = false  (src/ORBmatcher.cc:159-288)
+    // SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12)           strict = true   (src/ORBmatcher.cc:573-706)
+    // (include/ORBmatcher.h:62-63).  featVec1 / featVec2 are the DBoW2::FeatureVector of the two sides (node id ->
+    // feature indices); valid1[i]: feature i of side 1 owns a good map point; excluded2 (optional): features of
+    // side 2 that may not be matched (no good map point, :625-631).  matches12[i] = side-2 feature of side-1
+    // feature i or -1; matches21 the inverse.
+    int SearchByBoW(const std::map<unsigned, std::vector<unsigned> > &featVec1, const std::vector<orbcv::KeyPoint> &keys1,
+                    const orbcv::Mat &desc1, const std::vector<unsigned char> &valid1,
+                    const std::map<unsigned, std::vector<unsigned> > &featVec2, const std::vector<orbcv::KeyPoint> &keys2,
+                    const orbcv::Mat &desc2, const std::vector<unsigned char> *excluded2, bool strict,
+                    std::vector<int> &matches12, std::vector<int> &matches21)
+    {
+        const int n1 = (int)keys1.size(), n2 = (int)keys2.size();
+        matches12.assign(n1, -1); matches21.assign(n2, -1);
+        if (!handle_) return 0;
+        // intersection of the two sorted node maps (:180-264)
+        std::vector<orbgpu_wquery> q;
+        std::vector<unsigned char> qd;
+        std::vector<int32_t> qIndex, segStart(1, 0), segIndex;
+        std::map<unsigned, std::vector<unsigned> >::const_iterator it1 = featVec1.begin(), it2 = featVec2.begin();
+        while (it1 != featVec1.end() && it2 != featVec2.end()) {
+            if (it1->first == it2->first) {
+                const int32_t s = (int32_t)segStart.size() - 1;
+                for (size_t k = 0; k < it2->second.size(); k++) segIndex.push_back((int32_t)it2->second[k]);
+                segStart.push_back((int32_t)segIndex.size());
+                for (size_t k = 0; k < it1->second.size(); k++) {
+                    const unsigned i = it1->second[k];
+                    if (i >= (unsigned)n1 || !valid1[i]) continue;
+                    orbgpu_wquery w = orbgpu_wquery();
+                    w.angle = keys1[i].angle; w.minLevel = s; w.flags = 1;
+                    q.push_back(w);
+                    qIndex.push_back((int32_t)i);
+                    qd.insert(qd.end(), desc1.data + (size_t)i * 32, desc1.data + (size_t)i * 32 + 32);
+                }
+                ++it1; ++it2;
+            } else if (it1->first < it2->first) {
+                it1 = featVec1.lower_bound(it2->first);
+            } else {
+                it2 = featVec2.lower_bound(it1->first);
+            }
+        }
+        if (segIndex.empty()) segIndex.push_back(0);
+        std::vector<int32_t> assign(n2 > 0 ? n2 : 1, -1), qmatch(q.empty() ? 1 : q.size(), -1);
+        int32_t nmatches = 0;
+        if (check(orbgpu_search_by_bow(handle_, q.data(), qd.data(), (int32_t)q.size(),
+                                       reinterpret_cast<const orbgpu_keypoint *>(keys2.data()), desc2.data, n2, segStart.data(),
+                                       segIndex.data(), (int32_t)segStart.size() - 1, excluded2 ? excluded2->data() : nullptr,
+                                       strict ? TH_LOW - 1 : TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, assign.data(),
+                                       qmatch.data(), &nmatches)))
+            return 0;
+        for (size_t k = 0; k < q.size(); k++)
+            if (qmatch[k] >= 0) { matches12[qIndex[k]] = qmatch[k]; matches21[qmatch[k]] = qIndex[k]; }
         return nmatches;
     }
 

@@ -227,6 +227,26 @@ int orbgpu_make_shift_queries_device(orbgpu_matcher *m, int32_t npairs,
                                      const float *scale_host, int32_t nlevels,
                                      const float *bounds4_host, orbgpu_wquery *d_q);
 
+/* ORBmatcher::SearchByBoW, both overloads (src/ORBmatcher.cc:159-288 KeyFrame x Frame,
+ * :573-706 KeyFrame x KeyFrame).  The two FeatureVectors are intersected by the
+ * caller: segment s lists the train-side feature indices of the s-th common
+ * vocabulary node (seg_index[seg_start[s] .. seg_start[s+1])), and queries[] holds
+ * the query-side features that own a good map point in processing order (nodes
+ * ascending, index order inside a node) with flags bit0 = 1, angle = the
+ * keypoint angle and minLevel = the segment of their node (u, v, r, maxLevel, ur
+ * unused).  excluded[n2] (or NULL) marks train features that may not be matched
+ * (:625-631: no map point).  A query takes the nearest train feature of its
+ * segment that no earlier query took, if its distance is <= th_dist (TH_LOW for
+ * :228, TH_LOW-1 for the strict test of :649) and < nnratio * second best (256 if
+ * none); then the rotation-consistency filter (:267-285).  assign[n2]: query per
+ * train feature or -1; qmatch[nq] (or NULL): train feature per query or -1. */
+int orbgpu_search_by_bow(orbgpu_matcher *m, const orbgpu_wquery *queries, const uint8_t *query_desc,
+                         int32_t nq, const orbgpu_keypoint *kps2, const uint8_t *desc2, int32_t n2,
+                         const int32_t *seg_start, const int32_t *seg_index, int32_t nseg,
+                         const uint8_t *excluded, int32_t th_dist, float nnratio,
+                         int32_t check_orientation, int32_t *assign, int32_t *qmatch,
+                         int32_t *nmatches);
+
 /* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:422-571).
  * prev_matched_xy[2*n1] in/out (vbPrevMatched), matches12[n1] out. */
 int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1,

@@ -271,6 +271,18 @@ def search_by_projection(mode, queries, qdesc, kps2, desc2, bounds, uright2=None
     return n, assign[:len(kps2)].copy()
 
 
+def search_by_bow(queries, qdesc, kps2, desc2, seg_start, seg_index, excluded=None, th_dist=50, nnratio=0.7, checkOri=True):
+    q = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    kps2 = np.ascontiguousarray(kps2); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    ss = np.ascontiguousarray(seg_start, np.int32)
+    si = np.ascontiguousarray(seg_index, np.int32) if len(seg_index) else np.zeros(1, np.int32)
+    ex = None if excluded is None else np.ascontiguousarray(excluded, np.uint8)
+    assign = np.zeros(max(len(kps2), 1), np.int32); qmatch = np.zeros(max(len(q), 1), np.int32)
+    n = lib().orc_search_by_bow(_p(q), _p(qdesc), len(q), _p(kps2), _p(desc2), len(kps2), _p(ss), _p(si), _p(ex), th_dist,
+                                C.c_float(nnratio), int(checkOri), _p(assign), _p(qmatch))
+    return n, assign[:len(kps2)].copy(), qmatch[:len(q)].copy()
+
+
 def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, bf, b):
     """pyrL/pyrR: lists of contiguous 2-D uint8 level planes."""
     kpsL = np.ascontiguousarray(kpsL); kpsR = np.ascontiguousarray(kpsR)

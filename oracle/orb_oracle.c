@@ -1109,6 +1109,56 @@ int orc_search_by_projection(int mode, const orc_wquery *q, const uint8_t *qdesc
     return nmatches;
 }
 
+/* ORBmatcher::SearchByBoW (src/ORBmatcher.cc:159-288 and :573-706). */
+int orc_search_by_bow(const orc_wquery *q, const uint8_t *qdesc, int nq, const orc_keypoint *kps2,
+                      const uint8_t *desc2, int n2, const int32_t *seg_start,
+                      const int32_t *seg_index, const uint8_t *excluded, int th_dist,
+                      float nnratio, int checkOri, int32_t *assign, int32_t *qmatch)
+{
+    int nmatches = 0;
+    uint8_t *taken = (uint8_t *)calloc((size_t)(n2 > 0 ? n2 : 1), 1); /* vpMapPointMatches[i] != NULL / vbMatched2 */
+    ivec hist[ORC_HISTO_LENGTH];
+    memset(hist, 0, sizeof(hist));
+    for (int i = 0; i < n2; i++) assign[i] = -1;
+    for (int i = 0; i < nq; i++) qmatch[i] = -1;
+    for (int i = 0; i < nq; i++) {
+        if (!(q[i].flags & 1)) continue; /* :193-197 no (good) map point */
+        const int s = q[i].minLevel;
+        int bestDist1 = 256, bestIdx = -1, bestDist2 = 256;
+        for (int k = seg_start[s]; k < seg_start[s + 1]; k++) { /* :205-226 */
+            const int t = seg_index[k];
+            if (taken[t] || (excluded && excluded[t])) continue;
+            const int dist = orc_hamming256(qdesc + (size_t)i * 32, desc2 + (size_t)t * 32);
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx = t; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestIdx >= 0 && bestDist1 <= th_dist && (float)bestDist1 < nnratio * (float)bestDist2) { /* :228-230 */
+            assign[bestIdx] = i;
+            qmatch[i] = bestIdx;
+            taken[bestIdx] = 1;
+            if (checkOri) ivec_push(&hist[rot_bin(q[i].angle, kps2[bestIdx].angle)], i);
+            nmatches++;
+        }
+    }
+    if (checkOri) { /* :267-285 */
+        int sizes[ORC_HISTO_LENGTH], i1_, i2_, i3_;
+        for (int i = 0; i < ORC_HISTO_LENGTH; i++) sizes[i] = hist[i].n;
+        orc_three_maxima(sizes, ORC_HISTO_LENGTH, &i1_, &i2_, &i3_);
+        for (int i = 0; i < ORC_HISTO_LENGTH; i++) {
+            if (i == i1_ || i == i2_ || i == i3_) continue;
+            for (int j = 0; j < hist[i].n; j++) {
+                const int qi = hist[i].v[j];
+                assign[qmatch[qi]] = -1;
+                qmatch[qi] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < ORC_HISTO_LENGTH; i++) free(hist[i].v);
+    free(taken);
+    return nmatches;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774)                         */
 /* ------------------------------------------------------------------------ */

@@ -150,6 +150,17 @@ int orc_search_by_projection(int mode, const orc_wquery *q, const uint8_t *qdesc
                              const uint8_t *occupied, int32_t *assign, int th_dist,
                              float nnratio, int checkOri);
 
+/* ORBmatcher::SearchByBoW, both overloads (src/ORBmatcher.cc:159-288, 573-706), with
+ * the FeatureVector intersection done by the caller: q[] = query-side features
+ * owning a good map point, in processing order, q[i].minLevel = segment (common
+ * vocabulary node) of the query; segment s lists train features
+ * seg_index[seg_start[s] .. seg_start[s+1]).  excluded[n2] or NULL (:625-631).
+ * th_dist = TH_LOW for :228 (<=), TH_LOW-1 for :649 (<).  assign[n2], qmatch[nq] out. */
+int orc_search_by_bow(const orc_wquery *q, const uint8_t *qdesc, int nq, const orc_keypoint *kps2,
+                      const uint8_t *desc2, int n2, const int32_t *seg_start,
+                      const int32_t *seg_index, const uint8_t *excluded, int th_dist,
+                      float nnratio, int checkOri, int32_t *assign, int32_t *qmatch);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774). pyrL/pyrR: arrays of
  * nlevels interior pointers with strides. */
 int orc_stereo_matches(const orc_keypoint *kpsL, const uint8_t *descL, int nL,

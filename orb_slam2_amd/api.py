@@ -38,7 +38,7 @@ EXPORTS = [
     "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync",
     "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
-    "orbgpu_search_for_initialization", "orbgpu_stereo_match",
+    "orbgpu_search_by_bow", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
 ]
 
 
@@ -97,6 +97,7 @@ def load_library():
                                                                vp, vp, i32, f32, i32, vp]
         L.orbgpu_debug_window_stats.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
         L.orbgpu_make_shift_queries_device.argtypes = [vp, i32, vp, vp, i32, f32, f32, f32, vp, i32, vp, vp]
+        L.orbgpu_search_by_bow.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, f32, i32, vp, vp, C.POINTER(i32)]
         L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                        C.POINTER(i32)]
         L.orbgpu_stereo_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
@@ -264,6 +265,22 @@ class _PyramidView:
         return self._ex.pyramid_level(level)
 
 
+def bow_segments(featvec1, featvec2, valid1):
+    """Intersect two FeatureVectors (src/ORBmatcher.cc:175-264): for every common node, ascending,
+    the side-1 features with a good map point become queries (in the node's index order) and the
+    side-2 indices one segment.  Returns (q_index, q_seg, seg_start, seg_index) as int32 arrays."""
+    q_index, q_seg, seg_start, seg_index = [], [], [0], []
+    for node in sorted(set(featvec1) & set(featvec2)):
+        s = len(seg_start) - 1
+        seg_index.extend(int(t) for t in featvec2[node])
+        seg_start.append(len(seg_index))
+        for i in featvec1[node]:
+            if valid1 is None or valid1[i]:
+                q_index.append(int(i)); q_seg.append(s)
+    return (np.asarray(q_index, np.int32), np.asarray(q_seg, np.int32), np.asarray(seg_start, np.int32),
+            np.asarray(seg_index if seg_index else [0], np.int32))  # never an empty buffer; seg_start bounds its use
+
+
 class ORBmatcher:
     """Mirror of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:41-103): the distance
     primitive, the brute-force scan and the windowed searches."""
@@ -334,6 +351,33 @@ class ORBmatcher:
                                                      self.mfNNratio, int(self.mbCheckOrientation), C.byref(n)),
                "orbgpu_search_by_projection")
         return n.value, assign[:len(kps2)].copy()
+
+    def SearchByBoW(self, featvec1, kps1, desc1, valid1, featvec2, kps2, desc2, excluded2=None, strict=False):
+        """ORBmatcher::SearchByBoW (src/ORBmatcher.cc:159-288; strict=True: the KeyFrame x KeyFrame
+        overload :573-706 with `bestDist1 < TH_LOW`).  featvec1 / featvec2: DBoW2 FeatureVectors as
+        {node id: [feature indices]}; valid1[i]: feature i of side 1 owns a good map point.
+        Returns (nmatches, assign[n2] = side-1 feature per side-2 feature or -1,
+        matches12[n1] = side-2 feature per side-1 feature or -1)."""
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        q_index, q_seg, seg_start, seg_index = bow_segments(featvec1, featvec2, valid1)
+        q = np.zeros(max(len(q_index), 1), WQUERY_DTYPE)[:len(q_index)]
+        q["angle"] = kps1["angle"][q_index]; q["minLevel"] = q_seg; q["flags"] = 1
+        qd = np.ascontiguousarray(desc1[q_index]) if len(q_index) else np.zeros((0, 32), np.uint8)
+        ex = None if excluded2 is None else np.ascontiguousarray(excluded2, np.uint8)
+        assign = np.zeros(max(len(kps2), 1), np.int32); qm = np.zeros(max(len(q), 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_by_bow(self._h, _p(q), _p(qd), len(q), _p(kps2), _p(desc2), len(kps2), _p(seg_start),
+                                              _p(seg_index), len(seg_start) - 1, _p(ex), TH_LOW - 1 if strict else TH_LOW,
+                                              self.mfNNratio, int(self.mbCheckOrientation), _p(assign), _p(qm), C.byref(n)),
+               "orbgpu_search_by_bow")
+        assign = assign[:len(kps2)]
+        a1 = np.where(assign >= 0, q_index[np.clip(assign, 0, None)] if len(q_index) else -1, -1).astype(np.int32)
+        m12 = np.full(len(kps1), -1, np.int32)
+        qm = qm[:len(q)]
+        if len(q_index):
+            m12[q_index[qm >= 0]] = qm[qm >= 0]
+        return n.value, a1, m12
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds, vbPrevMatched, windowSize=10):
         """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""

@@ -14,7 +14,8 @@ __host__ __device__ inline size_t match_scratch_ints(int q_cap, int t_cap)
 
 struct ScaleTab { float s[ORBGPU_MAX_LEVELS]; };
 
-// mode 0..2: ORBGPU_MODE_*; mode 3: SearchForInitialization.
+// mode 0..2: ORBGPU_MODE_*; mode 3: SearchForInitialization; mode 4: SearchByBoW (the candidates of a
+// query are the train indices of one segment, seg_index[seg_start[s] .. seg_start[s+1]), s = q.minLevel).
 struct MatchArgs {
     int32_t mode;
     const orbgpu_wquery *q;
@@ -36,6 +37,7 @@ struct MatchArgs {
     int32_t check_orientation;
     int32_t *nmatches;  // [pair]
     int32_t *stats;     // optional [pair][4]: resolver iterations, window rescans
+    const int32_t *seg_start, *seg_index;  // mode 4 only (one pair)
 };
 
 #ifdef __HIPCC__

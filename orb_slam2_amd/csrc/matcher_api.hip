@@ -188,7 +188,8 @@ int orbgpu_hamming_bruteforce(orbgpu_matcher *m, const uint8_t *Q, int32_t nq, c
 static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orbgpu_wquery *d_q, const uint8_t *d_qdesc,
                       const int32_t *d_nq, int32_t q_cap, const orbgpu_keypoint *d_kps2, const uint8_t *d_desc2,
                       const float *d_uright2, const int32_t *d_n2, int32_t t_cap, const float *b4, const uint8_t *d_occ,
-                      int32_t *d_assign, int32_t *d_qmatch, int32_t th_dist, float nnratio, int32_t ori, int32_t *d_nmatches)
+                      int32_t *d_assign, int32_t *d_qmatch, int32_t th_dist, float nnratio, int32_t ori, int32_t *d_nmatches,
+                      const int32_t *d_seg_start = nullptr, const int32_t *d_seg_index = nullptr)
 {
     if (npairs < 1 || q_cap < 1 || t_cap < 1 || t_cap > (1 << 20) || !(b4[2] > b4[0]) || !(b4[3] > b4[1])) {
         set_error("window matcher: invalid sizes or bounds");
@@ -203,6 +204,7 @@ static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orb
     A.minX = b4[0]; A.minY = b4[1]; A.maxX = b4[2]; A.maxY = b4[3];
     A.occupied = d_occ; A.assign = d_assign; A.qmatch = d_qmatch; A.scratch = (int32_t *)m->scratch.p;
     A.th_dist = th_dist; A.nnratio = nnratio; A.check_orientation = ori; A.nmatches = d_nmatches;
+    A.seg_start = d_seg_start; A.seg_index = d_seg_index;
     if ((rc = m->stats.ensure((size_t)npairs * 16))) return rc;
     ORBGPU_HIP_CHECK(hipMemsetAsync(m->stats.p, 0, (size_t)npairs * 16, m->stream));
     A.stats = (int32_t *)m->stats.p;
@@ -243,7 +245,7 @@ int orbgpu_search_by_projection_batch_device(orbgpu_matcher *m, int32_t mode, in
 static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq,
                        const orbgpu_keypoint *kps2, const uint8_t *desc2, const float *uright2, int32_t n2, const float *b4,
                        const uint8_t *occupied, int32_t *assign, int32_t *qmatch, int32_t th_dist, float nnratio, int32_t ori,
-                       int32_t *nmatches)
+                       int32_t *nmatches, const int32_t *seg_start = nullptr, const int32_t *seg_index = nullptr, int32_t nseg = 0)
 {
     ORBGPU_HIP_CHECK(hipSetDevice(m->device));
     hipStream_t st = m->stream;
@@ -258,6 +260,13 @@ static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, 
     if ((rc = m->stage[6].ensure((size_t)tc * 4))) return rc;
     if ((rc = m->stage[7].ensure((size_t)qc * 4))) return rc;
     if ((rc = m->stage[8].ensure(64))) return rc;
+    const int32_t nidx = seg_start ? seg_start[nseg] : 0;
+    if (seg_start) {
+        if ((rc = m->stage[9].ensure((size_t)(nseg + 1) * 4))) return rc;
+        if ((rc = m->stage[10].ensure((size_t)(nidx > 0 ? nidx : 1) * 4))) return rc;
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[9].p, seg_start, (size_t)(nseg + 1) * 4, hipMemcpyHostToDevice, st));
+        if (nidx > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[10].p, seg_index, (size_t)nidx * 4, hipMemcpyHostToDevice, st));
+    }
     if (nq > 0) {
         ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, q, (size_t)nq * sizeof(orbgpu_wquery), hipMemcpyHostToDevice, st));
         ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[1].p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, st));
@@ -274,7 +283,8 @@ static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, 
     rc = run_window(m, mode, 1, (const orbgpu_wquery *)m->stage[0].p, (const uint8_t *)m->stage[1].p, dc, qc,
                     (const orbgpu_keypoint *)m->stage[2].p, (const uint8_t *)m->stage[3].p,
                     uright2 ? (const float *)m->stage[4].p : nullptr, dc + 1, tc, b4, occupied ? (const uint8_t *)m->stage[5].p : nullptr,
-                    (int32_t *)m->stage[6].p, (int32_t *)m->stage[7].p, th_dist, nnratio, ori, dc + 2);
+                    (int32_t *)m->stage[6].p, (int32_t *)m->stage[7].p, th_dist, nnratio, ori, dc + 2,
+                    seg_start ? (const int32_t *)m->stage[9].p : nullptr, seg_start ? (const int32_t *)m->stage[10].p : nullptr);
     if (rc) return rc;
     if (assign && n2 > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(assign, m->stage[6].p, (size_t)n2 * 4, hipMemcpyDeviceToHost, st));
     if (qmatch && nq > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(qmatch, m->stage[7].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
@@ -296,6 +306,34 @@ int orbgpu_search_by_projection(orbgpu_matcher *m, int32_t mode, const orbgpu_wq
     }
     return window_host(m, mode, q, qdesc, nq, kps2, desc2, uright2, n2, bounds4, occupied, assign, nullptr, th_dist, nnratio,
                        check_orientation, nmatches);
+}
+
+// ORBmatcher::SearchByBoW, both overloads (src/ORBmatcher.cc:159-288, 573-706): query i is compared
+// with the train features of vocabulary node segment queries[i].minLevel only.
+int orbgpu_search_by_bow(orbgpu_matcher *m, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq, const orbgpu_keypoint *kps2,
+                         const uint8_t *desc2, int32_t n2, const int32_t *seg_start, const int32_t *seg_index, int32_t nseg,
+                         const uint8_t *excluded, int32_t th_dist, float nnratio, int32_t check_orientation, int32_t *assign,
+                         int32_t *qmatch, int32_t *nmatches)
+{
+    if (!m || nq < 0 || n2 < 0 || nseg < 0 || (nq > 0 && (!q || !qdesc)) || (n2 > 0 && (!kps2 || !desc2)) || !seg_start ||
+        (nseg > 0 && !seg_index) || !nmatches || (n2 > 0 && !assign)) {
+        set_error("orbgpu_search_by_bow: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    // the kernels trust the segment tables: check them here
+    if (seg_start[0] != 0) { set_error("orbgpu_search_by_bow: seg_start[0] must be 0"); return ORBGPU_E_INVALID; }
+    for (int s = 0; s < nseg; s++)
+        if (seg_start[s + 1] < seg_start[s]) { set_error("orbgpu_search_by_bow: seg_start is not monotone"); return ORBGPU_E_INVALID; }
+    for (int k = 0; k < seg_start[nseg]; k++)
+        if (seg_index[k] < 0 || seg_index[k] >= n2) { set_error("orbgpu_search_by_bow: segment entry %d out of range", k); return ORBGPU_E_INVALID; }
+    for (int i = 0; i < nq; i++)
+        if ((q[i].flags & 1) && (q[i].minLevel < 0 || q[i].minLevel >= nseg)) {
+            set_error("orbgpu_search_by_bow: query %d names segment %d of %d", i, q[i].minLevel, nseg);
+            return ORBGPU_E_INVALID;
+        }
+    const float b4[4] = {0.f, 0.f, 1.f, 1.f};
+    return window_host(m, 4, q, qdesc, nq, kps2, desc2, nullptr, n2, b4, excluded, assign, qmatch, th_dist, nnratio,
+                       check_orientation, nmatches, seg_start, seg_index, nseg);
 }
 
 int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1, const uint8_t *desc1, int32_t n1,

@@ -46,6 +46,17 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
     const int lo = __shfl((int)(v & 0xFFFFFFFFull), src), hi = __shfl((int)(v >> 32), src);
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
+__device__ __forceinline__ void top2_wave_reduce(Top2 &t2)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long oa = shfl_xor_u64(t2.a, o), ob = shfl_xor_u64(t2.b, o);
+        const unsigned long long m1 = min(t2.a, oa);
+        const unsigned long long m2 = min(max(t2.a, oa), min(t2.b, ob));
+        t2.a = m1;
+        t2.b = m2;
+    }
+}
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
 #pragma unroll
@@ -205,7 +216,53 @@ __device__ __forceinline__ bool cand_useful(const MatchArgs &A, int dist)
 {
     if (A.mode == 3) return dist <= ORBGPU_TH_LOW || !((float)ORBGPU_TH_LOW < __fmul_rn((float)dist, A.nnratio));
     if (dist <= A.th_dist) return true;
+    if (A.mode == 4) return !((float)A.th_dist < __fmul_rn(A.nnratio, (float)dist));
     return A.mode == 0 && (float)A.th_dist > __fmul_rn(A.nnratio, (float)dist);
+}
+
+// One 64-candidate chunk into the per-query cache wk (kTopK keys, kNoKey = free): nk = entries in
+// use, npass = candidates seen so far.
+__device__ __forceinline__ void cache_insert_wave(unsigned long long key, unsigned long long *wk, int &nk, int &npass)
+{
+    const int lane = lane_id();
+    // The cache is an unordered set (the resolver takes minima): while it has
+    // room the chunk's candidates are appended by ballot rank; once it would
+    // overflow, candidates are taken in ascending order and evict the
+    // largest cached key, so the cache ends as the kTopK smallest keys.
+    const unsigned long long vb = __ballot(key != kNoKey);
+    const int nv = __popcll(vb);
+    npass += nv;
+    if (nk + nv <= kTopK) {
+        if (key != kNoKey) wk[nk + __popcll(vb & ((1ull << lane) - 1ull))] = key;
+        nk += nv;
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        uint32_t k32 = key == kNoKey ? 0xFFFFFFFFu : ((uint32_t)(key >> 40) << 22) | (uint32_t)((key >> 20) & 0xFFFFFu);
+        for (int rnd = 0; rnd < 64; rnd++) {
+            uint32_t m = k32;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+            if (m == 0xFFFFFFFFu) break;
+            const int src = __ffsll((long long)__ballot(k32 == m)) - 1;
+            const unsigned long long mk = shfl_u64(key, src);
+            if (lane == src) k32 = 0xFFFFFFFFu;
+            if (nk < kTopK) {
+                if (lane == 0) wk[nk] = mk;
+                nk++;
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+            // largest cached key and its slot
+            unsigned long long mx = lane < kTopK ? wk[lane] : 0ull;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = max(mx, shfl_xor_u64(mx, o));
+            mx = shfl_u64(mx, 0);
+            if (mk >= mx) break;  // later candidates of this chunk are larger still
+            const int slot = __ffsll((long long)__ballot(lane < kTopK && wk[lane] == mx)) - 1;
+            if (lane == 0) wk[slot] = mk;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
 // DYN = false: cache the kTopK best candidates of the window in wk (LDS, sorted)
@@ -281,56 +338,45 @@ __device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P
         if (DYN) {
             top2_push(t2, key);
         } else {
-            // The cache is an unordered set (the resolver takes minima): while it has
-            // room the chunk's candidates are appended by ballot rank; once it would
-            // overflow, candidates are taken in ascending order and evict the
-            // largest cached key, so the cache ends as the kTopK smallest keys.
-            const unsigned long long vb = __ballot(key != kNoKey);
-            const int nv = __popcll(vb);
-            npass += nv;
-            if (nk + nv <= kTopK) {
-                if (key != kNoKey) wk[nk + __popcll(vb & ((1ull << lane) - 1ull))] = key;
-                nk += nv;
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                uint32_t k32 = key == kNoKey ? 0xFFFFFFFFu : ((uint32_t)(key >> 40) << 22) | (uint32_t)((key >> 20) & 0xFFFFFu);
-                for (int rnd = 0; rnd < 64; rnd++) {
-                    uint32_t m = k32;
+            cache_insert_wave(key, wk, nk, npass);
+        }
+    }
+    if (DYN) top2_wave_reduce(t2);
+}
+
+// The candidates of a SearchByBoW query are the train features of its vocabulary node, in the
+// node's index order (src/ORBmatcher.cc:205-226, 621-647); one wave per query.
+template <bool DYN>
+__device__ __forceinline__ void scan_segment(const MatchArgs &A, const PairCtx &P, int i, const orbgpu_wquery &q,
+                                             unsigned long long *wk, Top2 &t2, int &npass)
+{
+    const int lane = lane_id();
+    t2.a = t2.b = kNoKey;
+    npass = 0;
+    int nk = 0;
+    const int b = A.seg_start[q.minLevel], total = A.seg_start[q.minLevel + 1] - b;
+    if (total <= 0) return;
+    uint32_t qd[8];
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
-                    if (m == 0xFFFFFFFFu) break;
-                    const int src = __ffsll((long long)__ballot(k32 == m)) - 1;
-                    const unsigned long long mk = shfl_u64(key, src);
-                    if (lane == src) k32 = 0xFFFFFFFFu;
-                    if (nk < kTopK) {
-                        if (lane == 0) wk[nk] = mk;
-                        nk++;
-                        __builtin_amdgcn_wave_barrier();
-                        continue;
-                    }
-                    // largest cached key and its slot
-                    unsigned long long mx = lane < kTopK ? wk[lane] : 0ull;
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) mx = max(mx, shfl_xor_u64(mx, o));
-                    mx = shfl_u64(mx, 0);
-                    if (mk >= mx) break;  // later candidates of this chunk are larger still
-                    const int slot = __ffsll((long long)__ballot(lane < kTopK && wk[lane] == mx)) - 1;
-                    if (lane == 0) wk[slot] = mk;
-                    __builtin_amdgcn_wave_barrier();
-                }
+    for (int k = 0; k < 8; k++) qd[k] = P.QD[(size_t)i * 8 + k];
+    for (int base = 0; base < total; base += 64) {
+        const int j = base + lane;
+        unsigned long long key = kNoKey;
+        if (j < total) {
+            const int t = A.seg_index[b + j];
+            if (!(P.OCC && P.OCC[t])) {
+                const uint4 d0 = reinterpret_cast<const uint4 *>(P.TD)[2 * (size_t)t];
+                const uint4 d1 = reinterpret_cast<const uint4 *>(P.TD)[2 * (size_t)t + 1];
+                const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
+                                 __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
+                if (cand_useful(A, dist) && (!DYN || !claimed_by_earlier(P, A.mode, 0, i, t, dist)))
+                    key = ((unsigned long long)dist << 40) | ((unsigned long long)j << 20) | (unsigned)t;
             }
         }
+        if (DYN) top2_push(t2, key);
+        else cache_insert_wave(key, wk, nk, npass);
     }
-    if (DYN) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long oa = shfl_xor_u64(t2.a, o), ob = shfl_xor_u64(t2.b, o);
-            const unsigned long long m1 = min(t2.a, oa);
-            const unsigned long long m2 = min(max(t2.a, oa), min(t2.b, ob));
-            t2.a = m1;
-            t2.b = m2;
-        }
-    }
+    if (DYN) top2_wave_reduce(t2);
 }
 
 // Two queries per wave, one per 32-lane half: the window setup and the final
@@ -455,26 +501,38 @@ __global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
     if (sub < kTopK) wk[w][half][sub] = kNoKey;
     __builtin_amdgcn_wave_barrier();
     const orbgpu_wquery q = P.Q[inq ? i : i0];
-    // window of this half's query (Frame::GetFeaturesInArea, src/Frame.cc:402-420)
-    const float r = q.r;
-    const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
-    const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
-    const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
-    const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
-    const bool live = inq && (q.flags & 1) && !(c0 >= ORBGPU_GRID_COLS || c1 < 0 || r0 >= ORBGPU_GRID_ROWS || r1 < 0);
-    const int ncols = live ? c1 - c0 + 1 : 0;
     int npass = 0;
-    if (__ballot(ncols > 32) == 0ull) {
-        scan_window_half(A, P, i, q, c0, ncols, r0, r1, wl[w] + 33 * half, ws[w] + 32 * half, wk[w][half], npass);
-    } else {
-        // a window wider than 32 grid columns: the full-wave scan, one query after the other
+    if (A.mode == 4) {
+        // vocabulary-node segments: the full-wave scan, one query after the other
         for (int h = 0; h < 2 && i0 + h < P.nq; h++) {
             const orbgpu_wquery qh = P.Q[i0 + h];
             Top2 t2;
             int np = 0;
-            if (qh.flags & 1) scan_window<false>(A, P, 0, i0 + h, qh, wl[w], ws[w], wk[w][h], t2, np);
+            if (qh.flags & 1) scan_segment<false>(A, P, i0 + h, qh, wk[w][h], t2, np);
             if (half == h) npass = np;
             __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // window of this half's query (Frame::GetFeaturesInArea, src/Frame.cc:402-420)
+        const float r = q.r;
+        const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
+        const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
+        const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
+        const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
+        const bool live = inq && (q.flags & 1) && !(c0 >= ORBGPU_GRID_COLS || c1 < 0 || r0 >= ORBGPU_GRID_ROWS || r1 < 0);
+        const int ncols = live ? c1 - c0 + 1 : 0;
+        if (__ballot(ncols > 32) == 0ull) {
+            scan_window_half(A, P, i, q, c0, ncols, r0, r1, wl[w] + 33 * half, ws[w] + 32 * half, wk[w][half], npass);
+        } else {
+            // a window wider than 32 grid columns: the full-wave scan, one query after the other
+            for (int h = 0; h < 2 && i0 + h < P.nq; h++) {
+                const orbgpu_wquery qh = P.Q[i0 + h];
+                Top2 t2;
+                int np = 0;
+                if (qh.flags & 1) scan_window<false>(A, P, 0, i0 + h, qh, wl[w], ws[w], wk[w][h], t2, np);
+                if (half == h) npass = np;
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -502,6 +560,9 @@ __device__ __forceinline__ void decide(const MatchArgs &A, const PairCtx &P, uin
     if (A.mode == 3) {  // src/ORBmatcher.cc:496-499
         const float best2 = b2 != kNoCand ? (float)cand_dist(b2) : 2147483648.0f;
         ok = best <= ORBGPU_TH_LOW && (float)best < __fmul_rn(best2, A.nnratio);
+    } else if (A.mode == 4) {  // src/ORBmatcher.cc:228-230, 649-651 (bestDist2 starts at 256)
+        const float best2 = b2 != kNoCand ? (float)cand_dist(b2) : 256.0f;
+        ok = best <= A.th_dist && (float)best < __fmul_rn(A.nnratio, best2);
     } else {
         ok = best <= A.th_dist;
         if (ok && A.mode == 0 && b2 != kNoCand) {  // ratio test only within one pyramid level (src/ORBmatcher.cc:118-121)
@@ -526,7 +587,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
     const int lane = lane_id(), wid = tid >> 6, nw = nt_ >> 6;
     PairCtx P = make_ctx(A, pair);
     const int nq = P.nq, n2 = P.n2, mode = A.mode;
-    const bool need2 = (mode == 0 || mode == 3);
+    const bool need2 = (mode == 0 || mode == 3 || mode == 4);
     if (lds_state) {
         int32_t *s = dyn_state;
         P.sel0 = s; s += A.q_cap;
@@ -601,7 +662,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
             const int s = selc[i];
             if (s < 0) continue;
             if (mode == 3) P.nxt[i] = atomicExch(&P.head[s], i);
-            else if (mode == 2 || ((i == tid ? qflags0 : P.Q[i].flags) & 2)) atomicMin(&P.head[s], i);
+            else if (mode == 2 || mode == 4 || ((i == tid ? qflags0 : P.Q[i].flags) & 2)) atomicMin(&P.head[s], i);
         }
         __syncthreads();
         if (tid < nq) evaluate(tid, key0, ncand0);
@@ -623,7 +684,8 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
             n_full++;
             Top2 t2;
             int npass;
-            scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
+            if (mode == 4) scan_segment<true>(A, P, i, P.Q[i], nullptr, t2, npass);
+            else scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
             if (lane == 0) {
                 int ns, nd;
                 decide(A, P, cand_pack(t2.a), cand_pack(t2.b), ns, nd);
@@ -735,7 +797,7 @@ __global__ __launch_bounds__(256) void k_shift_queries(const orbgpu_keypoint *__
 
 int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
 {
-    hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
+    if (A.mode != 4) hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(k_window_topk, dim3((A.q_cap + 7) / 8, npairs), dim3(256), 0, st, A);
     // selection state in LDS when it fits (6 words per query + 1 per train keypoint)
     const size_t state = (6 * (size_t)A.q_cap + (size_t)A.t_cap) * 4;

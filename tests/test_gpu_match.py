@@ -145,6 +145,56 @@ def test_search_for_initialization(oracle, frames, window, ratio, ori):
         assert n > 20
 
 
+def _featvec(desc, nbits):
+    """Stand-in for DBoW2's FeatureVector: node id = leading descriptor bits, so that similar descriptors
+    mostly share a node (the vocabulary file is not part of the reference checkout)."""
+    node = (desc[:, 0].astype(np.int32) >> (8 - nbits))
+    return {int(n): np.nonzero(node == n)[0].tolist() for n in np.unique(node)}
+
+
+@pytest.mark.parametrize("nbits,ratio,ori,strict", [(4, 0.7, True, False), (2, 0.9, True, True), (6, 0.75, False, False),
+                                                   (0, 0.8, True, True)])
+def test_search_by_bow(oracle, frames, nbits, ratio, ori, strict):
+    from orb_slam2_amd import api
+    m = api.ORBmatcher(ratio, ori)
+    (k1, d1), (k2, d2) = frames[0], frames[1]
+    rng = np.random.default_rng(nbits)
+    fv1, fv2 = _featvec(d1, nbits), _featvec(d2, nbits)
+    if nbits >= 4:  # nodes present on one side only exercise the lower_bound skips
+        fv1.pop(sorted(fv1)[1]); fv2.pop(sorted(fv2)[-2])
+    valid1 = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+    excl2 = (rng.random(len(k2)) < 0.1).astype(np.uint8) if strict else None
+    n, a1, m12 = m.SearchByBoW(fv1, k1, d1, valid1, fv2, k2, d2, excl2, strict)
+    qi, qs, ss, si = api.bow_segments(fv1, fv2, valid1)
+    q = np.zeros(len(qi), oracle.WQUERY_DTYPE)
+    q["angle"] = k1["angle"][qi]; q["minLevel"] = qs; q["flags"] = 1
+    rn, rassign, rqm = oracle.search_by_bow(q, d1[qi], k2.view(oracle.KEYPOINT_DTYPE), d2, ss, si, excl2,
+                                            49 if strict else 50, ratio, ori)
+    assert n == rn and n > 20
+    ra1 = np.where(rassign >= 0, qi[np.clip(rassign, 0, None)], -1)
+    assert np.array_equal(a1, ra1)
+    rm12 = np.full(len(k1), -1, np.int32); rm12[qi[rqm >= 0]] = rqm[rqm >= 0]
+    assert np.array_equal(m12, rm12)
+    assert (m12[valid1 == 0] == -1).all()
+    if excl2 is not None:
+        assert (a1[excl2 != 0] == -1).all()
+
+
+def test_search_by_bow_rejects_bad_segments(matcher):
+    from orb_slam2_amd import api
+    q = np.zeros(1, api.WQUERY_DTYPE); q["flags"] = 1; q["minLevel"] = 3
+    k2 = np.zeros(4, api.KEYPOINT_DTYPE)
+    n = api.C.c_int32()
+    lib = api.load_library()
+    args = (matcher._h, api._p(q), api._p(np.zeros((1, 32), np.uint8)), 1, api._p(k2), api._p(np.zeros((4, 32), np.uint8)), 4)
+    rc = lib.orbgpu_search_by_bow(*args, api._p(np.array([0, 2], np.int32)), api._p(np.array([0, 1], np.int32)), 1, None, 50, 0.7, 1,
+                                  api._p(np.zeros(4, np.int32)), None, api.C.byref(n))
+    assert rc != 0 and b"segment" in lib.orbgpu_last_error()
+    rc = lib.orbgpu_search_by_bow(*args, api._p(np.array([0, 2], np.int32)), api._p(np.array([0, 9], np.int32)), 1, None, 50, 0.7, 1,
+                                  api._p(np.zeros(4, np.int32)), None, api.C.byref(n))
+    assert rc != 0
+
+
 def test_window_match_empty_inputs(matcher):
     from orb_slam2_amd import api
     q = np.zeros(0, api.WQUERY_DTYPE)

@@ -452,6 +452,67 @@ def test_search_by_projection_last_frame_against_python(oracle, two_frames):
     assert n == cnt and np.array_equal(assign, ref) and cnt > 100
 
 
+@pytest.mark.parametrize("strict", [False, True])
+def test_search_by_bow_against_python(oracle, two_frames, strict):
+    """The reference's loops over the two FeatureVectors (src/ORBmatcher.cc:175-264, 596-683) written out in
+    Python on {node: [indices]} maps, against the oracle's segment form."""
+    from orb_slam2_amd import api
+    (k1, d1), (k2, d2) = two_frames
+    node1 = d1[:, 0] >> 5; node2 = d2[:, 0] >> 5
+    fv1 = {int(n): np.nonzero(node1 == n)[0].tolist() for n in np.unique(node1)}
+    fv2 = {int(n): np.nonzero(node2 == n)[0].tolist() for n in np.unique(node2)}
+    fv1.pop(sorted(fv1)[2]); fv2.pop(sorted(fv2)[0])
+    rng = np.random.default_rng(5)
+    valid1 = rng.random(len(k1)) < 0.85
+    has2 = rng.random(len(k2)) < 0.9 if strict else np.ones(len(k2), bool)
+    ratio = 0.8
+    # reference form
+    m12 = np.full(len(k1), -1); m21 = np.full(len(k2), -1); cnt = 0
+    hist = [[] for _ in range(30)]
+    n1s, n2s = sorted(fv1), sorted(fv2)
+    a = b = 0
+    while a < len(n1s) and b < len(n2s):
+        if n1s[a] == n2s[b]:
+            for i1 in fv1[n1s[a]]:
+                if not valid1[i1]:
+                    continue
+                best1, bidx, best2 = 256, -1, 256
+                for i2 in fv2[n2s[b]]:
+                    if m21[i2] >= 0 or not has2[i2]:
+                        continue
+                    d = _ham(d1[i1], d2[i2])
+                    if d < best1:
+                        best2, best1, bidx = best1, d, i2
+                    elif d < best2:
+                        best2 = d
+                ok = best1 < 50 if strict else best1 <= 50
+                if ok and np.float32(best1) < np.float32(ratio) * np.float32(best2):
+                    m12[i1] = bidx; m21[bidx] = i1; cnt += 1
+                    hist[_rot_bin(k1[i1]["angle"], k2[bidx]["angle"])].append(i1)
+            a += 1; b += 1
+        elif n1s[a] < n2s[b]:
+            while a < len(n1s) and n1s[a] < n2s[b]:
+                a += 1
+        else:
+            while b < len(n2s) and n2s[b] < n1s[a]:
+                b += 1
+    keep = _three_max([len(h) for h in hist])
+    for bi_, h in enumerate(hist):
+        if bi_ not in keep:
+            for i1 in h:
+                m21[m12[i1]] = -1; m12[i1] = -1; cnt -= 1
+    # oracle form
+    qi, qs, ss, si = api.bow_segments(fv1, fv2, valid1)
+    q = np.zeros(len(qi), oracle.WQUERY_DTYPE)
+    q["angle"] = k1["angle"][qi]; q["minLevel"] = qs; q["flags"] = 1
+    n, assign, qm = oracle.search_by_bow(q, d1[qi], k2, d2, ss, si, (~has2).astype(np.uint8) if strict else None,
+                                         49 if strict else 50, ratio, True)
+    om12 = np.full(len(k1), -1); om12[qi[qm >= 0]] = qm[qm >= 0]
+    om21 = np.where(assign >= 0, qi[np.clip(assign, 0, None)], -1)
+    assert n == cnt and cnt > 20
+    assert np.array_equal(om12, m12) and np.array_equal(om21, m21)
+
+
 def test_search_for_initialization_against_python(oracle, two_frames):
     (k1, d1), (k2, d2) = two_frames
     b = np.array([0, 0, 320, 240], np.float32)
