@@ -16,6 +16,7 @@
 
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ORBextractor.h"
@@ -126,6 +127,67 @@ public:
             return 0;
         for (size_t k = 0; k < q.size(); k++)
             if (qmatch[k] >= 0) { matches12[qIndex[k]] = qmatch[k]; matches21[qmatch[k]] = qIndex[k]; }
+        return nmatches;
+    }
+
+    // SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vMatchedPairs, bOnlyStereo)
+    // (include/ORBmatcher.h:73-74, src/ORBmatcher.cc:708-874).  keys = mvKeysUn, uRight = mvuRight (empty: monocular),
+    // hasMapPoint = GetMapPoint(i) != NULL, F12 row-major 3x3, (ex, ey) = epipole of camera 1 in image 2 (:714-721),
+    // scale2 / sigma2 = mvScaleFactors / mvLevelSigma2 of keyframe 2.
+    int SearchForTriangulation(const std::map<unsigned, std::vector<unsigned> > &featVec1, const std::vector<orbcv::KeyPoint> &keys1,
+                               const orbcv::Mat &desc1, const std::vector<unsigned char> &hasMapPoint1,
+                               const std::vector<float> &uRight1, const std::map<unsigned, std::vector<unsigned> > &featVec2,
+                               const std::vector<orbcv::KeyPoint> &keys2, const orbcv::Mat &desc2,
+                               const std::vector<unsigned char> &hasMapPoint2, const std::vector<float> &uRight2,
+                               const float F12[9], float ex, float ey, const std::vector<float> &scale2,
+                               const std::vector<float> &sigma2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs,
+                               bool bOnlyStereo)
+    {
+        const int n1 = (int)keys1.size(), n2 = (int)keys2.size();
+        vMatchedPairs.clear();
+        if (!handle_) return 0;
+        std::vector<orbgpu_wquery> q;
+        std::vector<unsigned char> qd;
+        std::vector<int32_t> qIndex, segStart(1, 0), segIndex;
+        std::map<unsigned, std::vector<unsigned> >::const_iterator it1 = featVec1.begin(), it2 = featVec2.begin();
+        while (it1 != featVec1.end() && it2 != featVec2.end()) {
+            if (it1->first == it2->first) {
+                const int32_t s = (int32_t)segStart.size() - 1;
+                for (size_t k = 0; k < it2->second.size(); k++) segIndex.push_back((int32_t)it2->second[k]);
+                segStart.push_back((int32_t)segIndex.size());
+                for (size_t k = 0; k < it1->second.size(); k++) {
+                    const unsigned i = it1->second[k];
+                    if (i >= (unsigned)n1 || hasMapPoint1[i]) continue;               // :750-754
+                    const bool stereo1 = !uRight1.empty() && uRight1[i] >= 0;
+                    if (bOnlyStereo && !stereo1) continue;                           // :758-760
+                    orbgpu_wquery w = orbgpu_wquery();
+                    w.u = keys1[i].pt.x; w.v = keys1[i].pt.y; w.angle = keys1[i].angle; w.minLevel = s; w.flags = stereo1 ? 5 : 1;
+                    q.push_back(w);
+                    qIndex.push_back((int32_t)i);
+                    qd.insert(qd.end(), desc1.data + (size_t)i * 32, desc1.data + (size_t)i * 32 + 32);
+                }
+                ++it1; ++it2;
+            } else if (it1->first < it2->first) {
+                it1 = featVec1.lower_bound(it2->first);
+            } else {
+                it2 = featVec2.lower_bound(it1->first);
+            }
+        }
+        if (segIndex.empty()) segIndex.push_back(0);
+        std::vector<int32_t> qmatch(q.empty() ? 1 : q.size(), -1);
+        int32_t nmatches = 0;
+        if (check(orbgpu_search_for_triangulation(handle_, q.data(), qd.data(), (int32_t)q.size(),
+                                                  reinterpret_cast<const orbgpu_keypoint *>(keys2.data()), desc2.data,
+                                                  uRight2.empty() ? nullptr : uRight2.data(), n2, segStart.data(), segIndex.data(),
+                                                  (int32_t)segStart.size() - 1, hasMapPoint2.data(), F12, ex, ey, scale2.data(),
+                                                  sigma2.data(), (int32_t)scale2.size(), bOnlyStereo ? 1 : 0,
+                                                  mbCheckOrientation ? 1 : 0, qmatch.data(), &nmatches)))
+            return 0;
+        std::vector<int> m12(n1, -1);
+        for (size_t k = 0; k < q.size(); k++)
+            if (qmatch[k] >= 0) m12[qIndex[k]] = qmatch[k];
+        for (int i = 0; i < n1; i++)  // :866-871
+            if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
         return nmatches;
     }
 

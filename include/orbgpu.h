@@ -247,6 +247,27 @@ int orbgpu_search_by_bow(orbgpu_matcher *m, const orbgpu_wquery *queries, const 
                          int32_t check_orientation, int32_t *assign, int32_t *qmatch,
                          int32_t *nmatches);
 
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:708-874): BoW-guided search
+ * between two keyframes for features without a map point, gated by the epipolar
+ * line.  Segments as in orbgpu_search_by_bow.  queries[]: the side-1 features
+ * without a map point (and with a stereo measurement if only_stereo), in
+ * processing order; u, v = undistorted keypoint position, angle, minLevel =
+ * segment, flags = 1 | (4 if mvuRight >= 0).  excluded[n2]: side-2 features that
+ * hold a map point; uright2[n2] or NULL (monocular).  F12: 3x3 row-major; (ex, ey):
+ * epipole in image 2 (:714-721); scale2 / sigma2: mvScaleFactors / mvLevelSigma2
+ * of keyframe 2.  A query takes the candidate of its node with the smallest
+ * distance <= TH_LOW that passes the gates (:789-806; the last one among equals);
+ * side-2 features are NOT made exclusive (the reference never sets vbMatched2).
+ * qmatch[nq]: side-2 feature per query or -1 after the rotation filter. */
+int orbgpu_search_for_triangulation(orbgpu_matcher *m, const orbgpu_wquery *queries,
+                                    const uint8_t *query_desc, int32_t nq,
+                                    const orbgpu_keypoint *kps2, const uint8_t *desc2,
+                                    const float *uright2, int32_t n2, const int32_t *seg_start,
+                                    const int32_t *seg_index, int32_t nseg, const uint8_t *excluded,
+                                    const float *F12, float ex, float ey, const float *scale2,
+                                    const float *sigma2, int32_t nlevels, int32_t only_stereo,
+                                    int32_t check_orientation, int32_t *qmatch, int32_t *nmatches);
+
 /* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:422-571).
  * prev_matched_xy[2*n1] in/out (vbPrevMatched), matches12[n1] out. */
 int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1,

@@ -283,6 +283,23 @@ def search_by_bow(queries, qdesc, kps2, desc2, seg_start, seg_index, excluded=No
     return n, assign[:len(kps2)].copy(), qmatch[:len(q)].copy()
 
 
+def search_for_triangulation(queries, qdesc, kps2, desc2, uright2, seg_start, seg_index, excluded, F12, ex, ey, scale2, sigma2,
+                             onlyStereo=False, checkOri=True):
+    q = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    kps2 = np.ascontiguousarray(kps2); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    ur = None if uright2 is None else np.ascontiguousarray(uright2, np.float32)
+    ss = np.ascontiguousarray(seg_start, np.int32)
+    si = np.ascontiguousarray(seg_index, np.int32) if len(seg_index) else np.zeros(1, np.int32)
+    exc = None if excluded is None else np.ascontiguousarray(excluded, np.uint8)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2, np.float32)
+    qmatch = np.zeros(max(len(q), 1), np.int32)
+    n = lib().orc_search_for_triangulation(_p(q), _p(qdesc), len(q), _p(kps2), _p(desc2), _p(ur), len(kps2), _p(ss), _p(si),
+                                           _p(exc), _p(F), C.c_float(ex), C.c_float(ey), _p(sc), _p(sg), int(onlyStereo),
+                                           int(checkOri), _p(qmatch))
+    return n, qmatch[:len(q)].copy()
+
+
 def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, bf, b):
     """pyrL/pyrR: lists of contiguous 2-D uint8 level planes."""
     kpsL = np.ascontiguousarray(kpsL); kpsR = np.ascontiguousarray(kpsR)

@@ -1159,6 +1159,71 @@ int orc_search_by_bow(const orc_wquery *q, const uint8_t *qdesc, int nq, const o
     return nmatches;
 }
 
+/* ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:140-157). */
+static int check_dist_epipolar_line(float x1, float y1, const orc_keypoint *kp2, const float *F12, const float *sigma2)
+{
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2[kp2->octave];
+}
+
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:708-874). */
+int orc_search_for_triangulation(const orc_wquery *q, const uint8_t *qdesc, int nq,
+                                 const orc_keypoint *kps2, const uint8_t *desc2, const float *uright2,
+                                 int n2, const int32_t *seg_start, const int32_t *seg_index,
+                                 const uint8_t *excluded, const float *F12, float ex, float ey,
+                                 const float *scale2, const float *sigma2, int onlyStereo,
+                                 int checkOri, int32_t *qmatch)
+{
+    (void)n2;
+    int nmatches = 0;
+    ivec hist[ORC_HISTO_LENGTH];
+    memset(hist, 0, sizeof(hist));
+    for (int i = 0; i < nq; i++) qmatch[i] = -1;
+    for (int i = 0; i < nq; i++) {
+        if (!(q[i].flags & 1)) continue;
+        const int bStereo1 = (q[i].flags & 4) != 0;
+        const int s = q[i].minLevel;
+        int bestDist = ORC_TH_LOW, bestIdx2 = -1;
+        for (int k = seg_start[s]; k < seg_start[s + 1]; k++) {
+            const int idx2 = seg_index[k];
+            if (excluded && excluded[idx2]) continue; /* vbMatched2 is never set by the reference (:776) */
+            const int bStereo2 = uright2 && uright2[idx2] >= 0;
+            if (onlyStereo && !bStereo2) continue;
+            const int dist = orc_hamming256(qdesc + (size_t)i * 32, desc2 + (size_t)idx2 * 32);
+            if (dist > ORC_TH_LOW || dist > bestDist) continue;
+            const orc_keypoint *kp2 = &kps2[idx2];
+            if (!bStereo1 && !bStereo2) {
+                const float distex = ex - kp2->x;
+                const float distey = ey - kp2->y;
+                if (distex * distex + distey * distey < 100 * scale2[kp2->octave]) continue;
+            }
+            if (check_dist_epipolar_line(q[i].u, q[i].v, kp2, F12, sigma2)) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+            qmatch[i] = bestIdx2;
+            nmatches++;
+            if (checkOri) ivec_push(&hist[rot_bin(q[i].angle, kps2[bestIdx2].angle)], i);
+        }
+    }
+    if (checkOri) {
+        int sizes[ORC_HISTO_LENGTH], i1_, i2_, i3_;
+        for (int i = 0; i < ORC_HISTO_LENGTH; i++) sizes[i] = hist[i].n;
+        orc_three_maxima(sizes, ORC_HISTO_LENGTH, &i1_, &i2_, &i3_);
+        for (int i = 0; i < ORC_HISTO_LENGTH; i++) {
+            if (i == i1_ || i == i2_ || i == i3_) continue;
+            for (int j = 0; j < hist[i].n; j++) { qmatch[hist[i].v[j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < ORC_HISTO_LENGTH; i++) free(hist[i].v);
+    return nmatches;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774)                         */
 /* ------------------------------------------------------------------------ */

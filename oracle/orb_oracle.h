@@ -161,6 +161,16 @@ int orc_search_by_bow(const orc_wquery *q, const uint8_t *qdesc, int nq, const o
                       const int32_t *seg_index, const uint8_t *excluded, int th_dist,
                       float nnratio, int checkOri, int32_t *assign, int32_t *qmatch);
 
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:708-874) with CheckDistEpipolarLine
+ * (:140-157), segment form as orc_search_by_bow.  q[i]: u, v = kp1 position, angle,
+ * minLevel = segment, flags = 1 | (4 if stereo).  qmatch[nq] out.  Returns nmatches. */
+int orc_search_for_triangulation(const orc_wquery *q, const uint8_t *qdesc, int nq,
+                                 const orc_keypoint *kps2, const uint8_t *desc2, const float *uright2,
+                                 int n2, const int32_t *seg_start, const int32_t *seg_index,
+                                 const uint8_t *excluded, const float *F12, float ex, float ey,
+                                 const float *scale2, const float *sigma2, int onlyStereo,
+                                 int checkOri, int32_t *qmatch);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774). pyrL/pyrR: arrays of
  * nlevels interior pointers with strides. */
 int orc_stereo_matches(const orc_keypoint *kpsL, const uint8_t *descL, int nL,

@@ -38,7 +38,7 @@ EXPORTS = [
     "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync",
     "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
-    "orbgpu_search_by_bow", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
+    "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
 ]
 
 
@@ -98,6 +98,8 @@ def load_library():
         L.orbgpu_debug_window_stats.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
         L.orbgpu_make_shift_queries_device.argtypes = [vp, i32, vp, vp, i32, f32, f32, f32, vp, i32, vp, vp]
         L.orbgpu_search_by_bow.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, f32, i32, vp, vp, C.POINTER(i32)]
+        L.orbgpu_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, f32, f32, vp, vp, i32,
+                                                      i32, i32, vp, C.POINTER(i32)]
         L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                        C.POINTER(i32)]
         L.orbgpu_stereo_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
@@ -378,6 +380,37 @@ class ORBmatcher:
         if len(q_index):
             m12[q_index[qm >= 0]] = qm[qm >= 0]
         return n.value, a1, m12
+
+    def SearchForTriangulation(self, featvec1, kps1, desc1, has_mp1, uright1, featvec2, kps2, desc2, has_mp2, uright2, F12,
+                               epipole, scale2, sigma2, bOnlyStereo=False):
+        """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:708-874).  kps = mvKeysUn, uright = mvuRight (None:
+        monocular), has_mp = feature already holds a map point, epipole = (ex, ey) of :714-721, scale2 / sigma2 =
+        mvScaleFactors / mvLevelSigma2 of keyframe 2.  Returns (nmatches, matches12[n1])."""
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        stereo1 = np.zeros(len(kps1), bool) if uright1 is None else np.asarray(uright1) >= 0
+        use1 = ~np.asarray(has_mp1, bool) & (stereo1 if bOnlyStereo else True)
+        q_index, q_seg, seg_start, seg_index = bow_segments(featvec1, featvec2, use1)
+        q = np.zeros(max(len(q_index), 1), WQUERY_DTYPE)[:len(q_index)]
+        q["u"] = kps1["x"][q_index]; q["v"] = kps1["y"][q_index]; q["angle"] = kps1["angle"][q_index]
+        q["minLevel"] = q_seg; q["flags"] = 1 + 4 * stereo1[q_index]
+        qd = np.ascontiguousarray(desc1[q_index]) if len(q_index) else np.zeros((0, 32), np.uint8)
+        ex2 = np.ascontiguousarray(has_mp2, np.uint8)
+        ur2 = None if uright2 is None else np.ascontiguousarray(uright2, np.float32)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2, np.float32)
+        qm = np.zeros(max(len(q), 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_for_triangulation(self._h, _p(q), _p(qd), len(q), _p(kps2), _p(desc2), _p(ur2), len(kps2),
+                                                         _p(seg_start), _p(seg_index), len(seg_start) - 1, _p(ex2), _p(F),
+                                                         float(epipole[0]), float(epipole[1]), _p(sc), _p(sg), len(sc),
+                                                         int(bOnlyStereo), int(self.mbCheckOrientation), _p(qm), C.byref(n)),
+               "orbgpu_search_for_triangulation")
+        m12 = np.full(len(kps1), -1, np.int32)
+        qm = qm[:len(q)]
+        if len(q_index):
+            m12[q_index[qm >= 0]] = qm[qm >= 0]
+        return n.value, m12
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds, vbPrevMatched, windowSize=10):
         """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""

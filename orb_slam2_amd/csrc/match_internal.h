@@ -15,7 +15,8 @@ __host__ __device__ inline size_t match_scratch_ints(int q_cap, int t_cap)
 struct ScaleTab { float s[ORBGPU_MAX_LEVELS]; };
 
 // mode 0..2: ORBGPU_MODE_*; mode 3: SearchForInitialization; mode 4: SearchByBoW (the candidates of a
-// query are the train indices of one segment, seg_index[seg_start[s] .. seg_start[s+1]), s = q.minLevel).
+// query are the train indices of one segment, seg_index[seg_start[s] .. seg_start[s+1]), s = q.minLevel);
+// mode 5: SearchForTriangulation (segments as in mode 4, epipolar gates, queries independent).
 struct MatchArgs {
     int32_t mode;
     const orbgpu_wquery *q;
@@ -37,7 +38,12 @@ struct MatchArgs {
     int32_t check_orientation;
     int32_t *nmatches;  // [pair]
     int32_t *stats;     // optional [pair][4]: resolver iterations, window rescans
-    const int32_t *seg_start, *seg_index;  // mode 4 only (one pair)
+    const int32_t *seg_start, *seg_index;  // modes 4 and 5 (one pair)
+    // mode 5 (SearchForTriangulation): fundamental matrix (row-major), epipole in the train image,
+    // per-level scale factors and sigma^2 of the train keyframe, bOnlyStereo
+    float F12[9], ex, ey;
+    ScaleTab scale2, sigma2;
+    int32_t only_stereo;
 };
 
 #ifdef __HIPCC__

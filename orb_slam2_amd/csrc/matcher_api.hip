@@ -189,7 +189,7 @@ static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orb
                       const int32_t *d_nq, int32_t q_cap, const orbgpu_keypoint *d_kps2, const uint8_t *d_desc2,
                       const float *d_uright2, const int32_t *d_n2, int32_t t_cap, const float *b4, const uint8_t *d_occ,
                       int32_t *d_assign, int32_t *d_qmatch, int32_t th_dist, float nnratio, int32_t ori, int32_t *d_nmatches,
-                      const int32_t *d_seg_start = nullptr, const int32_t *d_seg_index = nullptr)
+                      const int32_t *d_seg_start = nullptr, const int32_t *d_seg_index = nullptr, const MatchArgs *extra = nullptr)
 {
     if (npairs < 1 || q_cap < 1 || t_cap < 1 || t_cap > (1 << 20) || !(b4[2] > b4[0]) || !(b4[3] > b4[1])) {
         set_error("window matcher: invalid sizes or bounds");
@@ -198,6 +198,8 @@ static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orb
     int rc = m->scratch.ensure((size_t)npairs * match_scratch_ints(q_cap, t_cap) * 4);
     if (rc) return rc;
     MatchArgs A;
+    memset(&A, 0, sizeof(A));
+    if (extra) A = *extra;  // mode-specific fields (epipolar geometry of mode 5)
     A.mode = mode;
     A.q = d_q; A.qdesc = d_qdesc; A.nq = d_nq; A.q_cap = q_cap;
     A.kps2 = d_kps2; A.desc2 = d_desc2; A.uright2 = d_uright2; A.n2 = d_n2; A.t_cap = t_cap;
@@ -245,7 +247,8 @@ int orbgpu_search_by_projection_batch_device(orbgpu_matcher *m, int32_t mode, in
 static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq,
                        const orbgpu_keypoint *kps2, const uint8_t *desc2, const float *uright2, int32_t n2, const float *b4,
                        const uint8_t *occupied, int32_t *assign, int32_t *qmatch, int32_t th_dist, float nnratio, int32_t ori,
-                       int32_t *nmatches, const int32_t *seg_start = nullptr, const int32_t *seg_index = nullptr, int32_t nseg = 0)
+                       int32_t *nmatches, const int32_t *seg_start = nullptr, const int32_t *seg_index = nullptr, int32_t nseg = 0,
+                       const MatchArgs *extra = nullptr)
 {
     ORBGPU_HIP_CHECK(hipSetDevice(m->device));
     hipStream_t st = m->stream;
@@ -284,7 +287,7 @@ static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, 
                     (const orbgpu_keypoint *)m->stage[2].p, (const uint8_t *)m->stage[3].p,
                     uright2 ? (const float *)m->stage[4].p : nullptr, dc + 1, tc, b4, occupied ? (const uint8_t *)m->stage[5].p : nullptr,
                     (int32_t *)m->stage[6].p, (int32_t *)m->stage[7].p, th_dist, nnratio, ori, dc + 2,
-                    seg_start ? (const int32_t *)m->stage[9].p : nullptr, seg_start ? (const int32_t *)m->stage[10].p : nullptr);
+                    seg_start ? (const int32_t *)m->stage[9].p : nullptr, seg_start ? (const int32_t *)m->stage[10].p : nullptr, extra);
     if (rc) return rc;
     if (assign && n2 > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(assign, m->stage[6].p, (size_t)n2 * 4, hipMemcpyDeviceToHost, st));
     if (qmatch && nq > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(qmatch, m->stage[7].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
@@ -308,6 +311,23 @@ int orbgpu_search_by_projection(orbgpu_matcher *m, int32_t mode, const orbgpu_wq
                        check_orientation, nmatches);
 }
 
+// The kernels trust the segment tables of the BoW-guided matchers: check them on the host.
+static int check_segments(const char *who, const orbgpu_wquery *q, int32_t nq, int32_t n2, const int32_t *seg_start,
+                          const int32_t *seg_index, int32_t nseg)
+{
+    if (seg_start[0] != 0) { set_error("%s: seg_start[0] must be 0", who); return ORBGPU_E_INVALID; }
+    for (int s = 0; s < nseg; s++)
+        if (seg_start[s + 1] < seg_start[s]) { set_error("%s: seg_start is not monotone", who); return ORBGPU_E_INVALID; }
+    for (int k = 0; k < seg_start[nseg]; k++)
+        if (seg_index[k] < 0 || seg_index[k] >= n2) { set_error("%s: segment entry %d out of range", who, k); return ORBGPU_E_INVALID; }
+    for (int i = 0; i < nq; i++)
+        if ((q[i].flags & 1) && (q[i].minLevel < 0 || q[i].minLevel >= nseg)) {
+            set_error("%s: query %d names segment %d of %d", who, i, q[i].minLevel, nseg);
+            return ORBGPU_E_INVALID;
+        }
+    return ORBGPU_OK;
+}
+
 // ORBmatcher::SearchByBoW, both overloads (src/ORBmatcher.cc:159-288, 573-706): query i is compared
 // with the train features of vocabulary node segment queries[i].minLevel only.
 int orbgpu_search_by_bow(orbgpu_matcher *m, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq, const orbgpu_keypoint *kps2,
@@ -320,20 +340,41 @@ int orbgpu_search_by_bow(orbgpu_matcher *m, const orbgpu_wquery *q, const uint8_
         set_error("orbgpu_search_by_bow: invalid argument");
         return ORBGPU_E_INVALID;
     }
-    // the kernels trust the segment tables: check them here
-    if (seg_start[0] != 0) { set_error("orbgpu_search_by_bow: seg_start[0] must be 0"); return ORBGPU_E_INVALID; }
-    for (int s = 0; s < nseg; s++)
-        if (seg_start[s + 1] < seg_start[s]) { set_error("orbgpu_search_by_bow: seg_start is not monotone"); return ORBGPU_E_INVALID; }
-    for (int k = 0; k < seg_start[nseg]; k++)
-        if (seg_index[k] < 0 || seg_index[k] >= n2) { set_error("orbgpu_search_by_bow: segment entry %d out of range", k); return ORBGPU_E_INVALID; }
-    for (int i = 0; i < nq; i++)
-        if ((q[i].flags & 1) && (q[i].minLevel < 0 || q[i].minLevel >= nseg)) {
-            set_error("orbgpu_search_by_bow: query %d names segment %d of %d", i, q[i].minLevel, nseg);
-            return ORBGPU_E_INVALID;
-        }
+    int rc = check_segments("orbgpu_search_by_bow", q, nq, n2, seg_start, seg_index, nseg);
+    if (rc) return rc;
     const float b4[4] = {0.f, 0.f, 1.f, 1.f};
     return window_host(m, 4, q, qdesc, nq, kps2, desc2, nullptr, n2, b4, excluded, assign, qmatch, th_dist, nnratio,
                        check_orientation, nmatches, seg_start, seg_index, nseg);
+}
+
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:708-874).
+int orbgpu_search_for_triangulation(orbgpu_matcher *m, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq,
+                                    const orbgpu_keypoint *kps2, const uint8_t *desc2, const float *uright2, int32_t n2,
+                                    const int32_t *seg_start, const int32_t *seg_index, int32_t nseg, const uint8_t *excluded,
+                                    const float *F12, float ex, float ey, const float *scale2, const float *sigma2,
+                                    int32_t nlevels, int32_t only_stereo, int32_t check_orientation, int32_t *qmatch,
+                                    int32_t *nmatches)
+{
+    if (!m || nq < 0 || n2 < 0 || nseg < 0 || (nq > 0 && (!q || !qdesc || !qmatch)) || (n2 > 0 && (!kps2 || !desc2)) || !seg_start ||
+        (nseg > 0 && !seg_index) || !F12 || !scale2 || !sigma2 || nlevels < 1 || nlevels > ORBGPU_MAX_LEVELS || !nmatches) {
+        set_error("orbgpu_search_for_triangulation: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    int rc = check_segments("orbgpu_search_for_triangulation", q, nq, n2, seg_start, seg_index, nseg);
+    if (rc) return rc;
+    for (int t = 0; t < n2; t++)
+        if (kps2[t].octave < 0 || kps2[t].octave >= nlevels) {
+            set_error("orbgpu_search_for_triangulation: keypoint %d has octave %d of %d levels", t, kps2[t].octave, nlevels);
+            return ORBGPU_E_INVALID;
+        }
+    MatchArgs X;
+    memset(&X, 0, sizeof(X));
+    for (int k = 0; k < 9; k++) X.F12[k] = F12[k];
+    X.ex = ex; X.ey = ey; X.only_stereo = only_stereo;
+    for (int l = 0; l < nlevels; l++) { X.scale2.s[l] = scale2[l]; X.sigma2.s[l] = sigma2[l]; }
+    const float b4[4] = {0.f, 0.f, 1.f, 1.f};
+    return window_host(m, 5, q, qdesc, nq, kps2, desc2, uright2, n2, b4, excluded, nullptr, qmatch, ORBGPU_TH_LOW, 1.0f,
+                       check_orientation, nmatches, seg_start, seg_index, nseg, &X);
 }
 
 int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1, const uint8_t *desc1, int32_t n1,

@@ -217,6 +217,7 @@ __device__ __forceinline__ bool cand_useful(const MatchArgs &A, int dist)
     if (A.mode == 3) return dist <= ORBGPU_TH_LOW || !((float)ORBGPU_TH_LOW < __fmul_rn((float)dist, A.nnratio));
     if (dist <= A.th_dist) return true;
     if (A.mode == 4) return !((float)A.th_dist < __fmul_rn(A.nnratio, (float)dist));
+    if (A.mode == 5) return false;
     return A.mode == 0 && (float)A.th_dist > __fmul_rn(A.nnratio, (float)dist);
 }
 
@@ -359,18 +360,46 @@ __device__ __forceinline__ void scan_segment(const MatchArgs &A, const PairCtx &
     uint32_t qd[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) qd[k] = P.QD[(size_t)i * 8 + k];
+    // SearchForTriangulation: epipolar line of the query in the train image, l = x1' F12 (src/ORBmatcher.cc:143-145)
+    const bool tri = A.mode == 5, stereo1 = (q.flags & 4) != 0;
+    float la = 0.f, lb = 0.f, lc = 0.f;
+    if (tri) {
+        la = __fadd_rn(__fadd_rn(__fmul_rn(q.u, A.F12[0]), __fmul_rn(q.v, A.F12[3])), A.F12[6]);
+        lb = __fadd_rn(__fadd_rn(__fmul_rn(q.u, A.F12[1]), __fmul_rn(q.v, A.F12[4])), A.F12[7]);
+        lc = __fadd_rn(__fadd_rn(__fmul_rn(q.u, A.F12[2]), __fmul_rn(q.v, A.F12[5])), A.F12[8]);
+    }
     for (int base = 0; base < total; base += 64) {
         const int j = base + lane;
         unsigned long long key = kNoKey;
         if (j < total) {
             const int t = A.seg_index[b + j];
-            if (!(P.OCC && P.OCC[t])) {
+            bool ok = !(P.OCC && P.OCC[t]);
+            const bool stereo2 = tri && P.UR && P.UR[t] >= 0;
+            if (tri && A.only_stereo && !stereo2) ok = false;  // :779-783
+            if (ok) {
                 const uint4 d0 = reinterpret_cast<const uint4 *>(P.TD)[2 * (size_t)t];
                 const uint4 d1 = reinterpret_cast<const uint4 *>(P.TD)[2 * (size_t)t + 1];
                 const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
                                  __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
-                if (cand_useful(A, dist) && (!DYN || !claimed_by_earlier(P, A.mode, 0, i, t, dist)))
+                if (tri) {
+                    if (dist <= A.th_dist) {  // :789
+                        const orbgpu_keypoint k2 = P.K2[t];
+                        bool pass = true;
+                        if (!stereo1 && !stereo2) {  // too close to the epipole (:794-800)
+                            const float dx = __fsub_rn(A.ex, k2.x), dy = __fsub_rn(A.ey, k2.y);
+                            if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.0f, A.scale2.s[k2.octave])) pass = false;
+                        }
+                        if (pass) {  // CheckDistEpipolarLine (:147-156), the 3.84 comparison is done in double
+                            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2.x), __fmul_rn(lb, k2.y)), lc);
+                            const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+                            pass = den != 0.0f && (double)__fdiv_rn(__fmul_rn(num, num), den) < __dmul_rn(3.84, (double)A.sigma2.s[k2.octave]);
+                        }
+                        // `dist > bestDist` skips (:789): among equal distances the last candidate wins
+                        if (pass) key = ((unsigned long long)dist << 40) | ((unsigned long long)(0xFFFFFu - (unsigned)j) << 20) | (unsigned)t;
+                    }
+                } else if (cand_useful(A, dist) && (!DYN || !claimed_by_earlier(P, A.mode, 0, i, t, dist))) {
                     key = ((unsigned long long)dist << 40) | ((unsigned long long)j << 20) | (unsigned)t;
+                }
             }
         }
         if (DYN) top2_push(t2, key);
@@ -502,7 +531,7 @@ __global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
     __builtin_amdgcn_wave_barrier();
     const orbgpu_wquery q = P.Q[inq ? i : i0];
     int npass = 0;
-    if (A.mode == 4) {
+    if (A.mode >= 4) {
         // vocabulary-node segments: the full-wave scan, one query after the other
         for (int h = 0; h < 2 && i0 + h < P.nq; h++) {
             const orbgpu_wquery qh = P.Q[i0 + h];
@@ -560,6 +589,8 @@ __device__ __forceinline__ void decide(const MatchArgs &A, const PairCtx &P, uin
     if (A.mode == 3) {  // src/ORBmatcher.cc:496-499
         const float best2 = b2 != kNoCand ? (float)cand_dist(b2) : 2147483648.0f;
         ok = best <= ORBGPU_TH_LOW && (float)best < __fmul_rn(best2, A.nnratio);
+    } else if (A.mode == 5) {  // src/ORBmatcher.cc:809: any surviving candidate is a match
+        ok = true;
     } else if (A.mode == 4) {  // src/ORBmatcher.cc:228-230, 649-651 (bestDist2 starts at 256)
         const float best2 = b2 != kNoCand ? (float)cand_dist(b2) : 256.0f;
         ok = best <= A.th_dist && (float)best < __fmul_rn(A.nnratio, best2);
@@ -684,7 +715,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
             n_full++;
             Top2 t2;
             int npass;
-            if (mode == 4) scan_segment<true>(A, P, i, P.Q[i], nullptr, t2, npass);
+            if (mode >= 4) scan_segment<true>(A, P, i, P.Q[i], nullptr, t2, npass);
             else scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
             if (lane == 0) {
                 int ns, nd;
@@ -754,6 +785,9 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
             if (mode == 3) {
                 // only a live match is removed (:551-559); i is the only writer of assign[s] here
                 if (assign[s] == i) { assign[s] = -1; atomicSub(&sh_changed, 1); }
+            } else if (mode == 5) {
+                selc[i] = -1;  // vMatches12[idx1] = -1 (:856); train features are not exclusive in this matcher
+                atomicSub(&sh_changed, 1);
             } else {
                 // every entry of a losing bin clears its train keypoint and decrements (:1507-1517)
                 assign[s] = -1;
@@ -765,7 +799,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
     if (P.qmatch) {
         for (int i = tid; i < nq; i += nt_) {
             const int s = selc[i];
-            P.qmatch[i] = (s >= 0 && assign[s] == i) ? s : -1;
+            P.qmatch[i] = (s >= 0 && (mode == 5 || assign[s] == i)) ? s : -1;
         }
     }
     if (tid == 0) A.nmatches[pair] = sh_changed;
@@ -797,7 +831,7 @@ __global__ __launch_bounds__(256) void k_shift_queries(const orbgpu_keypoint *__
 
 int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
 {
-    if (A.mode != 4) hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
+    if (A.mode < 4) hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(k_window_topk, dim3((A.q_cap + 7) / 8, npairs), dim3(256), 0, st, A);
     // selection state in LDS when it fits (6 words per query + 1 per train keypoint)
     const size_t state = (6 * (size_t)A.q_cap + (size_t)A.t_cap) * 4;

@@ -180,6 +180,39 @@ def test_search_by_bow(oracle, frames, nbits, ratio, ori, strict):
         assert (a1[excl2 != 0] == -1).all()
 
 
+@pytest.mark.parametrize("nbits,stereo,only_stereo,ori", [(3, False, False, True), (2, True, False, True), (4, True, True, False),
+                                                           (0, False, False, True)])
+def test_search_for_triangulation(oracle, frames, nbits, stereo, only_stereo, ori):
+    """Frames 0 and 1 differ by an image-plane shift of (2, 1) px: F12 = [t]x with t = (2, 1, 0) makes the
+    epipolar lines run along the shift, so true correspondences pass CheckDistEpipolarLine and most others fail."""
+    from orb_slam2_amd import api
+    m = api.ORBmatcher(0.6, ori)
+    (k1, d1), (k2, d2) = frames[0], frames[1]
+    rng = np.random.default_rng(40 + nbits)
+    fv1, fv2 = _featvec(d1, nbits), _featvec(d2, nbits)
+    has1 = rng.random(len(k1)) < 0.2; has2 = rng.random(len(k2)) < 0.2
+    ur1 = np.where(rng.random(len(k1)) < 0.6, k1["x"] - 7.0, -1.0).astype(np.float32) if stereo else None
+    ur2 = np.where(rng.random(len(k2)) < 0.6, k2["x"] - 7.0, -1.0).astype(np.float32) if stereo else None
+    t = np.array([2.0, 1.0], np.float32) / np.float32(np.sqrt(5.0))
+    F12 = np.array([[0, 0, t[1]], [0, 0, -t[0]], [-t[1], t[0], 0]], np.float32)
+    epipole = (300.0, 200.0)  # inside the image, so the "too close to the epipole" gate fires for some candidates
+    tab = oracle.tables(oracle.make_params(1000))
+    scale2 = tab["scale"]; sigma2 = (scale2 * scale2).astype(np.float32)
+    n, m12 = m.SearchForTriangulation(fv1, k1, d1, has1, ur1, fv2, k2, d2, has2, ur2, F12, epipole, scale2, sigma2, only_stereo)
+    stereo1 = np.zeros(len(k1), bool) if ur1 is None else ur1 >= 0
+    use1 = ~has1 & (stereo1 if only_stereo else True)
+    qi, qs, ss, si = api.bow_segments(fv1, fv2, use1)
+    q = np.zeros(len(qi), oracle.WQUERY_DTYPE)
+    q["u"] = k1["x"][qi]; q["v"] = k1["y"][qi]; q["angle"] = k1["angle"][qi]; q["minLevel"] = qs; q["flags"] = 1 + 4 * stereo1[qi]
+    rn, rqm = oracle.search_for_triangulation(q, d1[qi], k2.view(oracle.KEYPOINT_DTYPE), d2, ur2, ss, si, has2.astype(np.uint8),
+                                              F12, epipole[0], epipole[1], scale2, sigma2, only_stereo, ori)
+    rm12 = np.full(len(k1), -1, np.int32); rm12[qi[rqm >= 0]] = rqm[rqm >= 0]
+    assert n == rn and np.array_equal(m12, rm12)
+    assert n > 20 and (m12[has1] == -1).all()
+    hit = m12[m12 >= 0]
+    assert not has2[hit].any()
+
+
 def test_search_by_bow_rejects_bad_segments(matcher):
     from orb_slam2_amd import api
     q = np.zeros(1, api.WQUERY_DTYPE); q["flags"] = 1; q["minLevel"] = 3
