@@ -191,6 +191,30 @@ public:
         return nmatches;
     }
 
+    // The keypoint search inside Fuse(KeyFrame*, vpMapPoints, th) (chi2Gate = true), Fuse(KeyFrame*, Scw, ...) and
+    // both directions of SearchBySim3 (thDist = TH_HIGH) (include/ORBmatcher.h:77-89, src/ORBmatcher.cc:876-1377):
+    // queries[i] is the projection window of map point i with minLevel = predicted-1, maxLevel = predicted; every
+    // query independently takes the nearest keypoint.  bestIdx[i] = keypoint or -1.  The map surgery of Fuse and
+    // the mutual-agreement step of SearchBySim3 (:1356-1374) stay with the caller.
+    int SearchInArea(const std::vector<orbgpu_wquery> &queries, const orbcv::Mat &queryDesc,
+                     const std::vector<orbcv::KeyPoint> &keysUn, const orbcv::Mat &descriptors, const std::vector<float> *uRight,
+                     const float bounds[4], const std::vector<float> *invLevelSigma2, bool chi2Gate, int thDist,
+                     std::vector<int> &bestIdx)
+    {
+        const int nq = (int)queries.size(), n2 = (int)keysUn.size();
+        bestIdx.assign(nq, -1);
+        if (!handle_ || nq == 0) return 0;
+        int32_t nmatches = 0;
+        if (check(orbgpu_search_in_area(handle_, queries.data(), queryDesc.data, nq,
+                                        reinterpret_cast<const orbgpu_keypoint *>(keysUn.data()), descriptors.data,
+                                        uRight ? uRight->data() : nullptr, n2, bounds,
+                                        invLevelSigma2 ? invLevelSigma2->data() : nullptr,
+                                        invLevelSigma2 ? (int32_t)invLevelSigma2->size() : 0, chi2Gate ? 1 : 0, thDist,
+                                        bestIdx.data(), &nmatches)))
+            return 0;
+        return nmatches;
+    }
+
     // reference: include/ORBmatcher.h:70, src/ORBmatcher.cc:422-571
     int SearchForInitialization(const std::vector<orbcv::KeyPoint> &keys1, const orbcv::Mat &desc1,
                                 const std::vector<orbcv::KeyPoint> &keys2, const orbcv::Mat &desc2, const float bounds[4],

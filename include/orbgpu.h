@@ -268,6 +268,23 @@ int orbgpu_search_for_triangulation(orbgpu_matcher *m, const orbgpu_wquery *quer
                                     const float *sigma2, int32_t nlevels, int32_t only_stereo,
                                     int32_t check_orientation, int32_t *qmatch, int32_t *nmatches);
 
+/* The keypoint search shared by ORBmatcher::Fuse (src/ORBmatcher.cc:876-1010 and
+ * :1012-1151) and ORBmatcher::SearchBySim3 (:1153-1377): query i (a projected map
+ * point: u, v, r = th*scale[predicted level], minLevel = predicted-1, maxLevel =
+ * predicted, ur, flags bit0) takes the keypoint of KeyFrame::GetFeaturesInArea
+ * (src/KeyFrame.cc:585-624) with the smallest descriptor distance (first one among
+ * equals) if it is <= th_dist (TH_LOW for Fuse, TH_HIGH for SearchBySim3).  Queries
+ * do not influence each other.  chi2_gate != 0 adds the reprojection test of
+ * :945-975 (7.8 with a stereo measurement uright2[t] >= 0, else 5.99, scaled by
+ * inv_sigma2[octave] = mvInvLevelSigma2).  qmatch[nq]: keypoint per query or -1;
+ * the map surgery of Fuse and the mutual-agreement step of SearchBySim3
+ * (:1356-1374) stay with the caller. */
+int orbgpu_search_in_area(orbgpu_matcher *m, const orbgpu_wquery *queries, const uint8_t *query_desc,
+                          int32_t nq, const orbgpu_keypoint *kps2, const uint8_t *desc2,
+                          const float *uright2, int32_t n2, const float *bounds4,
+                          const float *inv_sigma2, int32_t nlevels, int32_t chi2_gate,
+                          int32_t th_dist, int32_t *qmatch, int32_t *nmatches);
+
 /* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:422-571).
  * prev_matched_xy[2*n1] in/out (vbPrevMatched), matches12[n1] out. */
 int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1,

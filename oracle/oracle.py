@@ -300,6 +300,18 @@ def search_for_triangulation(queries, qdesc, kps2, desc2, uright2, seg_start, se
     return n, qmatch[:len(q)].copy()
 
 
+def search_in_area(queries, qdesc, kps2, desc2, bounds, uright2=None, inv_sigma2=None, chi2_gate=False, th_dist=50):
+    q = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    kps2 = np.ascontiguousarray(kps2); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    b = np.asarray(bounds, np.float32)
+    ur = None if uright2 is None else np.ascontiguousarray(uright2, np.float32)
+    sg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    qmatch = np.zeros(max(len(q), 1), np.int32)
+    n = lib().orc_search_in_area(_p(q), _p(qdesc), len(q), _p(kps2), _p(desc2), _p(ur), len(kps2), _p(b), _p(sg), int(chi2_gate),
+                                 th_dist, _p(qmatch))
+    return n, qmatch[:len(q)].copy()
+
+
 def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, bf, b):
     """pyrL/pyrR: lists of contiguous 2-D uint8 level planes."""
     kpsL = np.ascontiguousarray(kpsL); kpsR = np.ascontiguousarray(kpsR)

@@ -1224,6 +1224,49 @@ int orc_search_for_triangulation(const orc_wquery *q, const uint8_t *qdesc, int 
     return nmatches;
 }
 
+/* Candidate loops of ORBmatcher::Fuse (src/ORBmatcher.cc:929-979, 1097-1115) and
+ * ORBmatcher::SearchBySim3 (:1240-1256, 1320-1336). */
+int orc_search_in_area(const orc_wquery *q, const uint8_t *qdesc, int nq, const orc_keypoint *kps2,
+                       const uint8_t *desc2, const float *uright2, int n2, const float *bounds4,
+                       const float *inv_sigma2, int chi2_gate, int th_dist, int32_t *qmatch)
+{
+    int nmatches = 0;
+    int32_t *cs = (int32_t *)malloc(sizeof(int32_t) * (ORC_GRID_COLS * ORC_GRID_ROWS + 1));
+    int32_t *ci = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
+    orc_grid_build(kps2, n2, bounds4, cs, ci);
+    for (int i = 0; i < nq; i++) {
+        qmatch[i] = -1;
+        if (!(q[i].flags & 1)) continue;
+        const float u = q[i].u, v = q[i].v, ur = q[i].ur;
+        /* KeyFrame::GetFeaturesInArea has no level filter; the callers apply [predicted-1, predicted] right after */
+        const int nc = orc_features_in_area(kps2, bounds4, cs, ci, u, v, q[i].r, -1, -1, cand, n2);
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            const orc_keypoint *kp = &kps2[idx];
+            const int kpLevel = kp->octave;
+            if (kpLevel < q[i].minLevel || kpLevel > q[i].maxLevel) continue;
+            if (chi2_gate) {
+                if (uright2 && uright2[idx] >= 0) {
+                    const float ex = u - kp->x, ey = v - kp->y, er = ur - uright2[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u - kp->x, ey = v - kp->y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = orc_hamming256(qdesc + (size_t)i * 32, desc2 + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestIdx >= 0 && bestDist <= th_dist) { qmatch[i] = bestIdx; nmatches++; }
+    }
+    free(cs); free(ci); free(cand);
+    return nmatches;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774)                         */
 /* ------------------------------------------------------------------------ */

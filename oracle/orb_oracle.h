@@ -171,6 +171,15 @@ int orc_search_for_triangulation(const orc_wquery *q, const uint8_t *qdesc, int 
                                  const float *scale2, const float *sigma2, int onlyStereo,
                                  int checkOri, int32_t *qmatch);
 
+/* The window search of ORBmatcher::Fuse (src/ORBmatcher.cc:876-1010, 1012-1151) and
+ * ORBmatcher::SearchBySim3 (:1153-1377) on KeyFrame::GetFeaturesInArea
+ * (src/KeyFrame.cc:585-624): per query the nearest keypoint with octave in
+ * [minLevel, maxLevel], optionally behind the chi-square gate of :945-975.
+ * qmatch[nq] out; returns the number of queries with a match. */
+int orc_search_in_area(const orc_wquery *q, const uint8_t *qdesc, int nq, const orc_keypoint *kps2,
+                       const uint8_t *desc2, const float *uright2, int n2, const float *bounds4,
+                       const float *inv_sigma2, int chi2_gate, int th_dist, int32_t *qmatch);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774). pyrL/pyrR: arrays of
  * nlevels interior pointers with strides. */
 int orc_stereo_matches(const orc_keypoint *kpsL, const uint8_t *descL, int nL,

@@ -38,7 +38,7 @@ EXPORTS = [
     "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync",
     "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
-    "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
+    "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_in_area", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
 ]
 
 
@@ -100,6 +100,7 @@ def load_library():
         L.orbgpu_search_by_bow.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, f32, i32, vp, vp, C.POINTER(i32)]
         L.orbgpu_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, f32, f32, vp, vp, i32,
                                                       i32, i32, vp, C.POINTER(i32)]
+        L.orbgpu_search_in_area.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
         L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                        C.POINTER(i32)]
         L.orbgpu_stereo_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
@@ -411,6 +412,22 @@ class ORBmatcher:
         if len(q_index):
             m12[q_index[qm >= 0]] = qm[qm >= 0]
         return n.value, m12
+
+    def SearchInArea(self, queries, qdesc, kps2, desc2, bounds, uright2=None, inv_sigma2=None, chi2_gate=False, th_dist=TH_LOW):
+        """The keypoint search inside ORBmatcher::Fuse (src/ORBmatcher.cc:876-1151; chi2_gate=True for the first
+        overload) and ORBmatcher::SearchBySim3 (:1153-1377, th_dist=TH_HIGH, once per direction): every query
+        independently takes the nearest keypoint of its window.  Returns (nmatches, qmatch[nq])."""
+        q = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        kps2 = np.ascontiguousarray(kps2); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        ur = None if uright2 is None else np.ascontiguousarray(uright2, np.float32)
+        sg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+        qm = np.zeros(max(len(q), 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_in_area(self._h, _p(q), _p(qdesc), len(q), _p(kps2), _p(desc2), _p(ur), len(kps2), _p(b),
+                                               _p(sg), 0 if sg is None else len(sg), int(chi2_gate), th_dist, _p(qm), C.byref(n)),
+               "orbgpu_search_in_area")
+        return n.value, qm[:len(q)].copy()
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds, vbPrevMatched, windowSize=10):
         """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""

@@ -16,7 +16,9 @@ struct ScaleTab { float s[ORBGPU_MAX_LEVELS]; };
 
 // mode 0..2: ORBGPU_MODE_*; mode 3: SearchForInitialization; mode 4: SearchByBoW (the candidates of a
 // query are the train indices of one segment, seg_index[seg_start[s] .. seg_start[s+1]), s = q.minLevel);
-// mode 5: SearchForTriangulation (segments as in mode 4, epipolar gates, queries independent).
+// mode 5: SearchForTriangulation (segments as in mode 4, epipolar gates, queries independent);
+// mode 6: best keypoint in a window per query, queries independent (Fuse x2, SearchBySim3), optional
+// reprojection chi-square gate of Fuse(pKF, vpMapPoints, th).
 struct MatchArgs {
     int32_t mode;
     const orbgpu_wquery *q;
@@ -44,6 +46,9 @@ struct MatchArgs {
     float F12[9], ex, ey;
     ScaleTab scale2, sigma2;
     int32_t only_stereo;
+    // mode 6: chi-square gate on/off and mvInvLevelSigma2 of the keyframe
+    int32_t chi2_gate;
+    ScaleTab inv_sigma2;
 };
 
 #ifdef __HIPCC__

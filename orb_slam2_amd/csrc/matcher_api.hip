@@ -377,6 +377,32 @@ int orbgpu_search_for_triangulation(orbgpu_matcher *m, const orbgpu_wquery *q, c
                        check_orientation, nmatches, seg_start, seg_index, nseg, &X);
 }
 
+// The window search shared by Fuse (src/ORBmatcher.cc:876-1010, 1012-1151) and SearchBySim3
+// (:1153-1377): every query independently takes the nearest keypoint of its window.
+int orbgpu_search_in_area(orbgpu_matcher *m, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq, const orbgpu_keypoint *kps2,
+                          const uint8_t *desc2, const float *uright2, int32_t n2, const float *bounds4, const float *inv_sigma2,
+                          int32_t nlevels, int32_t chi2_gate, int32_t th_dist, int32_t *qmatch, int32_t *nmatches)
+{
+    if (!m || nq < 0 || n2 < 0 || (nq > 0 && (!q || !qdesc || !qmatch)) || (n2 > 0 && (!kps2 || !desc2)) || !bounds4 || !nmatches ||
+        (chi2_gate && (!inv_sigma2 || nlevels < 1 || nlevels > ORBGPU_MAX_LEVELS))) {
+        set_error("orbgpu_search_in_area: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    MatchArgs X;
+    memset(&X, 0, sizeof(X));
+    X.chi2_gate = chi2_gate ? 1 : 0;
+    if (chi2_gate) {
+        for (int t = 0; t < n2; t++)
+            if (kps2[t].octave < 0 || kps2[t].octave >= nlevels) {
+                set_error("orbgpu_search_in_area: keypoint %d has octave %d of %d levels", t, kps2[t].octave, nlevels);
+                return ORBGPU_E_INVALID;
+            }
+        for (int l = 0; l < nlevels; l++) X.inv_sigma2.s[l] = inv_sigma2[l];
+    }
+    return window_host(m, 6, q, qdesc, nq, kps2, desc2, chi2_gate ? uright2 : nullptr, n2, bounds4, nullptr, nullptr, qmatch, th_dist,
+                       1.0f, 0, nmatches, nullptr, nullptr, 0, &X);
+}
+
 int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1, const uint8_t *desc1, int32_t n1,
                                      const orbgpu_keypoint *kps2, const uint8_t *desc2, int32_t n2, const float *bounds4,
                                      float *prev_matched_xy, int32_t *matches12, int32_t window_size, float nnratio,

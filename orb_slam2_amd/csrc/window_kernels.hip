@@ -217,8 +217,23 @@ __device__ __forceinline__ bool cand_useful(const MatchArgs &A, int dist)
     if (A.mode == 3) return dist <= ORBGPU_TH_LOW || !((float)ORBGPU_TH_LOW < __fmul_rn((float)dist, A.nnratio));
     if (dist <= A.th_dist) return true;
     if (A.mode == 4) return !((float)A.th_dist < __fmul_rn(A.nnratio, (float)dist));
-    if (A.mode == 5) return false;
+    if (A.mode >= 5) return false;  // modes 5 and 6: only candidates within the threshold matter
     return A.mode == 0 && (float)A.th_dist > __fmul_rn(A.nnratio, (float)dist);
+}
+
+// Reprojection chi-square gate of Fuse (src/ORBmatcher.cc:945-975): 7.8 with a stereo
+// measurement, 5.99 without; the products are float, the comparisons double.
+__device__ __forceinline__ bool reprojection_gate(const MatchArgs &A, const PairCtx &P, const orbgpu_wquery &q, const int4 &rec, int t)
+{
+    const float ex = __fsub_rn(q.u, __int_as_float(rec.x)), ey = __fsub_rn(q.v, __int_as_float(rec.y));
+    const float inv = A.inv_sigma2.s[rec.z];
+    float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+    if (P.UR && P.UR[t] >= 0) {
+        const float er = __fsub_rn(q.ur, P.UR[t]);
+        e2 = __fadd_rn(e2, __fmul_rn(er, er));
+        return !((double)__fmul_rn(e2, inv) > 7.8);
+    }
+    return !((double)__fmul_rn(e2, inv) > 5.99);
 }
 
 // One 64-candidate chunk into the per-query cache wk (kTopK keys, kNoKey = free): nk = entries in
@@ -327,7 +342,8 @@ __device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P
             if (ok && !(fabsf(__fsub_rn(__int_as_float(rec.x), q.u)) < r && fabsf(__fsub_rn(__int_as_float(rec.y), q.v)) < r)) ok = false;
             if (ok && mode != 3) {
                 if (P.OCC && P.OCC[t]) ok = false;
-                if (ok && mode != 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
+                if (ok && mode < 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
+                if (ok && mode == 6 && A.chi2_gate) ok = reprojection_gate(A, P, q, rec, t);
             }
             if (ok) {
                 const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
@@ -461,7 +477,8 @@ __device__ __forceinline__ void scan_window_half(const MatchArgs &A, const PairC
             if (ok && !(fabsf(__fsub_rn(__int_as_float(rec.x), q.u)) < r && fabsf(__fsub_rn(__int_as_float(rec.y), q.v)) < r)) ok = false;
             if (ok && mode != 3) {
                 if (P.OCC && P.OCC[t]) ok = false;
-                if (ok && mode != 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
+                if (ok && mode < 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
+                if (ok && mode == 6 && A.chi2_gate) ok = reprojection_gate(A, P, q, rec, t);
             }
             if (ok) {
                 // the descriptor is fetched only for entries inside the window and the level range (a minority)
@@ -531,7 +548,7 @@ __global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
     __builtin_amdgcn_wave_barrier();
     const orbgpu_wquery q = P.Q[inq ? i : i0];
     int npass = 0;
-    if (A.mode >= 4) {
+    if (A.mode == 4 || A.mode == 5) {
         // vocabulary-node segments: the full-wave scan, one query after the other
         for (int h = 0; h < 2 && i0 + h < P.nq; h++) {
             const orbgpu_wquery qh = P.Q[i0 + h];
@@ -591,6 +608,8 @@ __device__ __forceinline__ void decide(const MatchArgs &A, const PairCtx &P, uin
         ok = best <= ORBGPU_TH_LOW && (float)best < __fmul_rn(best2, A.nnratio);
     } else if (A.mode == 5) {  // src/ORBmatcher.cc:809: any surviving candidate is a match
         ok = true;
+    } else if (A.mode == 6) {  // src/ORBmatcher.cc:981, 1117, 1258
+        ok = best <= A.th_dist;
     } else if (A.mode == 4) {  // src/ORBmatcher.cc:228-230, 649-651 (bestDist2 starts at 256)
         const float best2 = b2 != kNoCand ? (float)cand_dist(b2) : 256.0f;
         ok = best <= A.th_dist && (float)best < __fmul_rn(A.nnratio, best2);
@@ -693,7 +712,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
             const int s = selc[i];
             if (s < 0) continue;
             if (mode == 3) P.nxt[i] = atomicExch(&P.head[s], i);
-            else if (mode == 2 || mode == 4 || ((i == tid ? qflags0 : P.Q[i].flags) & 2)) atomicMin(&P.head[s], i);
+            else if (mode < 5 && (mode == 2 || mode == 4 || ((i == tid ? qflags0 : P.Q[i].flags) & 2))) atomicMin(&P.head[s], i);
         }
         __syncthreads();
         if (tid < nq) evaluate(tid, key0, ncand0);
@@ -715,7 +734,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
             n_full++;
             Top2 t2;
             int npass;
-            if (mode >= 4) scan_segment<true>(A, P, i, P.Q[i], nullptr, t2, npass);
+            if (mode == 4 || mode == 5) scan_segment<true>(A, P, i, P.Q[i], nullptr, t2, npass);
             else scan_window<true>(A, P, cur, i, P.Q[i], wl[wid], ws[wid], nullptr, t2, npass);
             if (lane == 0) {
                 int ns, nd;
@@ -785,8 +804,8 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
             if (mode == 3) {
                 // only a live match is removed (:551-559); i is the only writer of assign[s] here
                 if (assign[s] == i) { assign[s] = -1; atomicSub(&sh_changed, 1); }
-            } else if (mode == 5) {
-                selc[i] = -1;  // vMatches12[idx1] = -1 (:856); train features are not exclusive in this matcher
+            } else if (mode >= 5) {
+                selc[i] = -1;  // vMatches12[idx1] = -1 (:856); train features are not exclusive in these matchers
                 atomicSub(&sh_changed, 1);
             } else {
                 // every entry of a losing bin clears its train keypoint and decrements (:1507-1517)
@@ -799,7 +818,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
     if (P.qmatch) {
         for (int i = tid; i < nq; i += nt_) {
             const int s = selc[i];
-            P.qmatch[i] = (s >= 0 && (mode == 5 || assign[s] == i)) ? s : -1;
+            P.qmatch[i] = (s >= 0 && (mode >= 5 || assign[s] == i)) ? s : -1;
         }
     }
     if (tid == 0) A.nmatches[pair] = sh_changed;
@@ -831,7 +850,7 @@ __global__ __launch_bounds__(256) void k_shift_queries(const orbgpu_keypoint *__
 
 int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
 {
-    if (A.mode < 4) hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
+    if (A.mode != 4 && A.mode != 5) hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(k_window_topk, dim3((A.q_cap + 7) / 8, npairs), dim3(256), 0, st, A);
     // selection state in LDS when it fits (6 words per query + 1 per train keypoint)
     const size_t state = (6 * (size_t)A.q_cap + (size_t)A.t_cap) * 4;

@@ -213,6 +213,33 @@ def test_search_for_triangulation(oracle, frames, nbits, stereo, only_stereo, or
     assert not has2[hit].any()
 
 
+@pytest.mark.parametrize("th,chi2,stereo,th_dist", [(3.0, True, True, 50), (4.0, True, False, 50), (7.5, False, False, 100),
+                                                    (40.0, False, False, 50)])
+def test_search_in_area(matcher, oracle, frames, th, chi2, stereo, th_dist):
+    """The window search of Fuse (chi-square gate) and SearchBySim3: independent queries, level range
+    [predicted-1, predicted], nearest keypoint; several queries may name the same keypoint."""
+    from orb_slam2_amd import api
+    (k1, d1), (k2, d2) = frames[0], frames[1]
+    sc = oracle.tables(oracle.make_params(1000))["scale"]
+    q = api.shift_queries(k1, -2.0, -1.0, th, sc, _bounds())
+    rng = np.random.default_rng(int(th))
+    q["minLevel"] = k1["octave"] - 1; q["maxLevel"] = k1["octave"]
+    q["u"] += rng.normal(0, 1.0, len(q)).astype(np.float32); q["v"] += rng.normal(0, 1.0, len(q)).astype(np.float32)
+    q["ur"] = q["u"] - 6.0
+    q["flags"] = np.where(rng.random(len(q)) < 0.1, 0, 3)  # bit 1 must be ignored here
+    q = q.astype(api.WQUERY_DTYPE)
+    ur2 = np.where(rng.random(len(k2)) < 0.5, k2["x"] - 6.0 + rng.normal(0, 1.0, len(k2)), -1.0).astype(np.float32) if stereo else None
+    inv_s2 = (1.0 / (sc * sc)).astype(np.float32)
+    n, qm = matcher.SearchInArea(q, d1, k2, d2, _bounds(), ur2, inv_s2, chi2, th_dist)
+    rn, rqm = oracle.search_in_area(q.view(oracle.WQUERY_DTYPE), d1, k2.view(oracle.KEYPOINT_DTYPE), d2, _bounds(), ur2, inv_s2,
+                                    chi2, th_dist)
+    assert n == rn and np.array_equal(qm, rqm)
+    assert n > 100 and (qm[q["flags"] == 0] == -1).all()
+    if th >= 40:
+        hits = qm[qm >= 0]
+        assert len(np.unique(hits)) < len(hits)  # keypoints shared between queries
+
+
 def test_search_by_bow_rejects_bad_segments(matcher):
     from orb_slam2_amd import api
     q = np.zeros(1, api.WQUERY_DTYPE); q["flags"] = 1; q["minLevel"] = 3

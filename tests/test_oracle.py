@@ -576,6 +576,83 @@ def test_search_for_triangulation_against_python(oracle, two_frames):
     assert n == cnt and cnt > 10 and np.array_equal(om12, m12)
 
 
+@pytest.mark.parametrize("chi2", [False, True])
+def test_search_in_area_against_python(oracle, two_frames, chi2):
+    """Candidate loops of Fuse (src/ORBmatcher.cc:929-979, with the chi-square gate) and of Fuse(Scw) / SearchBySim3
+    (:1097-1115, 1240-1256) in Python on the grid restatement."""
+    from orb_slam2_amd import api
+    f32 = np.float32
+    (k1, d1), (k2, d2) = two_frames
+    b = np.array([0, 0, 320, 240], f32)
+    sc = oracle.tables(oracle.make_params(500))["scale"]
+    q = api.shift_queries(k1, -2.0, -1.0, 4.0, sc, b)
+    q["minLevel"] = k1["octave"] - 1; q["maxLevel"] = k1["octave"]; q["ur"] = q["u"] - 3.0
+    rng = np.random.default_rng(2)
+    ur2 = np.where(rng.random(len(k2)) < 0.5, k2["x"] - 3.5, -1.0).astype(f32)
+    inv_s2 = (1.0 / (sc * sc)).astype(f32)
+    n, qm = oracle.search_in_area(q.view(oracle.WQUERY_DTYPE), d1, k2, d2, b, ur2, inv_s2, chi2, 50)
+    cells, invw, invh = _grid_py(k2, b)
+    ref = np.full(len(q), -1); cnt = 0
+    for i, qi in enumerate(q):
+        if not qi["flags"] & 1:
+            continue
+        best, bidx = 256, -1
+        for t in _area_py(k2, cells, invw, invh, b, qi["u"], qi["v"], qi["r"], -1, -1):
+            lvl = k2[t]["octave"]
+            if lvl < qi["minLevel"] or lvl > qi["maxLevel"]:
+                continue
+            if chi2:
+                ex, ey = f32(qi["u"] - k2[t]["x"]), f32(qi["v"] - k2[t]["y"])
+                if ur2[t] >= 0:
+                    er = f32(qi["ur"] - ur2[t])
+                    e2 = f32(f32(f32(ex * ex) + f32(ey * ey)) + f32(er * er))
+                    if float(f32(e2 * inv_s2[lvl])) > 7.8:
+                        continue
+                else:
+                    e2 = f32(f32(ex * ex) + f32(ey * ey))
+                    if float(f32(e2 * inv_s2[lvl])) > 5.99:
+                        continue
+            d = _ham(d1[i], d2[t])
+            if d < best:
+                best, bidx = d, t
+        if best <= 50:
+            ref[i] = bidx; cnt += 1
+    assert n == cnt and cnt > 50 and np.array_equal(qm, ref)
+
+
+def test_keyframe_projection_overload_is_mode_keyframe(oracle, two_frames):
+    """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:362-398): nearest unmatched
+    keypoint of the window with level in [predicted-1, predicted], accepted at <= TH_LOW, a match makes the keypoint
+    unavailable to later points, no rotation check -- i.e. mode 2 of orc_search_by_projection with th_dist 50."""
+    from orb_slam2_amd import api
+    (k1, d1), (k2, d2) = two_frames
+    b = np.array([0, 0, 320, 240], np.float32)
+    sc = oracle.tables(oracle.make_params(500))["scale"]
+    q = api.shift_queries(k1, -2.0, -1.0, 10.0, sc, b)
+    q["minLevel"] = k1["octave"] - 1; q["maxLevel"] = k1["octave"]
+    rng = np.random.default_rng(6)
+    already = rng.random(len(k2)) < 0.15
+    n, assign = oracle.search_by_projection(2, q.view(oracle.WQUERY_DTYPE), d1, k2, d2, b, occupied=already.astype(np.uint8),
+                                            th_dist=50, checkOri=False)
+    cells, invw, invh = _grid_py(k2, b)
+    matched = already.copy(); ref = np.full(len(k2), -1); cnt = 0
+    for i, qi in enumerate(q):
+        if not qi["flags"] & 1:
+            continue
+        best, bidx = 256, -1
+        for t in _area_py(k2, cells, invw, invh, b, qi["u"], qi["v"], qi["r"], -1, -1):
+            if matched[t]:
+                continue
+            if k2[t]["octave"] < qi["minLevel"] or k2[t]["octave"] > qi["maxLevel"]:
+                continue
+            d = _ham(d1[i], d2[t])
+            if d < best:
+                best, bidx = d, t
+        if best <= 50:
+            ref[bidx] = i; matched[bidx] = True; cnt += 1
+    assert n == cnt and cnt > 50 and np.array_equal(assign, ref)
+
+
 def test_search_for_initialization_against_python(oracle, two_frames):
     (k1, d1), (k2, d2) = two_frames
     b = np.array([0, 0, 320, 240], np.float32)
