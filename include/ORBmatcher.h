@@ -215,6 +215,41 @@ public:
         return nmatches;
     }
 
+    // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:262-340) for many map points at once: the observations of
+    // map point p are rows start[p] .. start[p+1]-1 of observed; bestIdx[p] = the representative's offset in that range.
+    int ComputeDistinctiveDescriptors(const orbcv::Mat &observed, const std::vector<int> &start, std::vector<int> &bestIdx)
+    {
+        const int np = (int)start.size() - 1;
+        bestIdx.assign(np > 0 ? np : 0, -1);
+        if (!handle_ || np <= 0) return 0;
+        return check(orbgpu_distinctive_descriptors(handle_, observed.data, start.data(), np, bestIdx.data(), nullptr));
+    }
+
+    // Frame::AssignFeaturesToGrid (src/Frame.cc:270-293): CSR over the 64x48 cells, cell = ix*48 + iy.
+    int AssignFeaturesToGrid(const std::vector<orbcv::KeyPoint> &keysUn, const float bounds[4], std::vector<int> &cellStart,
+                             std::vector<int> &cellIndex)
+    {
+        cellStart.assign(ORBGPU_GRID_COLS * ORBGPU_GRID_ROWS + 1, 0);
+        cellIndex.assign(keysUn.empty() ? 1 : keysUn.size(), 0);
+        if (!handle_) return 0;
+        int32_t n = 0;
+        const int rc = check(orbgpu_assign_features_to_grid(handle_, reinterpret_cast<const orbgpu_keypoint *>(keysUn.data()),
+                                                            (int32_t)keysUn.size(), bounds, cellStart.data(), cellIndex.data(), &n));
+        cellIndex.resize(rc ? 0 : n);
+        return rc;
+    }
+
+    // Frame::ComputeStereoFromRGBD (src/Frame.cc:777-798): depth = CV_32F image rows of strideFloats floats.
+    int ComputeStereoFromRGBD(const std::vector<orbcv::KeyPoint> &keys, const std::vector<orbcv::KeyPoint> &keysUn, const float *depth,
+                              int w, int h, int strideFloats, float bf, std::vector<float> &mvuRight, std::vector<float> &mvDepth)
+    {
+        mvuRight.assign(keys.size(), -1.0f); mvDepth.assign(keys.size(), -1.0f);
+        if (!handle_ || keys.empty()) return 0;
+        return check(orbgpu_stereo_from_rgbd(handle_, reinterpret_cast<const orbgpu_keypoint *>(keys.data()),
+                                             reinterpret_cast<const orbgpu_keypoint *>(keysUn.data()), (int32_t)keys.size(), depth, w, h,
+                                             strideFloats, bf, mvuRight.data(), mvDepth.data()));
+    }
+
     // reference: include/ORBmatcher.h:70, src/ORBmatcher.cc:422-571
     int SearchForInitialization(const std::vector<orbcv::KeyPoint> &keys1, const orbcv::Mat &desc1,
                                 const std::vector<orbcv::KeyPoint> &keys2, const orbcv::Mat &desc2, const float bounds[4],

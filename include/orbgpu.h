@@ -285,6 +285,32 @@ int orbgpu_search_in_area(orbgpu_matcher *m, const orbgpu_wquery *queries, const
                           const float *inv_sigma2, int32_t nlevels, int32_t chi2_gate,
                           int32_t th_dist, int32_t *qmatch, int32_t *nmatches);
 
+/* Frame::AssignFeaturesToGrid (src/Frame.cc:270-293) with Frame::PosInGrid
+ * (:485-500): the 64x48 grid over bounds4 = {mnMinX, mnMinY, mnMaxX, mnMaxY} as
+ * CSR.  Cell (ix, iy) has number ix*48 + iy; cell_start[64*48 + 1];
+ * cell_index[n] lists the keypoints of every cell in insertion (index) order;
+ * keypoints outside the grid are left out (n_in_grid of n are listed). */
+int orbgpu_assign_features_to_grid(orbgpu_matcher *m, const orbgpu_keypoint *kps_un, int32_t n,
+                                   const float *bounds4, int32_t *cell_start, int32_t *cell_index,
+                                   int32_t *n_in_grid);
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:262-340) for a batch of
+ * map points: the observations of map point p are descriptors
+ * desc[start[p] .. start[p+1]) (32 bytes each).  best_idx[p] = offset within
+ * that range of the descriptor with the smallest median distance to all of them
+ * (first one among equals; median = element (int)(0.5*(N-1)) of the sorted row,
+ * self distance included), -1 if the range is empty; best_median[p] (or NULL). */
+int orbgpu_distinctive_descriptors(orbgpu_matcher *m, const uint8_t *desc, const int32_t *start,
+                                   int32_t npoints, int32_t *best_idx, int32_t *best_median);
+
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:777-798): depth[h][stride_floats] is
+ * the float depth image; kps the distorted keypoints (lookup position, truncated
+ * to int), kps_un the undistorted ones.  uright[i] = kps_un[i].x - bf/d and
+ * out_depth[i] = d where d > 0, else both -1. */
+int orbgpu_stereo_from_rgbd(orbgpu_matcher *m, const orbgpu_keypoint *kps, const orbgpu_keypoint *kps_un,
+                            int32_t n, const float *depth, int32_t w, int32_t h, int32_t stride_floats,
+                            float bf, float *uright, float *out_depth);
+
 /* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:422-571).
  * prev_matched_xy[2*n1] in/out (vbPrevMatched), matches12[n1] out. */
 int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1,

@@ -312,6 +312,23 @@ def search_in_area(queries, qdesc, kps2, desc2, bounds, uright2=None, inv_sigma2
     return n, qmatch[:len(q)].copy()
 
 
+def distinctive_descriptors(desc, start):
+    desc = np.ascontiguousarray(desc, np.uint8); start = np.ascontiguousarray(start, np.int32)
+    n = len(start) - 1
+    bi = np.zeros(max(n, 1), np.int32); bm = np.zeros(max(n, 1), np.int32)
+    lib().orc_distinctive_descriptors(_p(desc), _p(start), n, _p(bi), _p(bm))
+    return bi[:n].copy(), bm[:n].copy()
+
+
+def stereo_from_rgbd(kps, kps_un, depth, bf):
+    kps = np.ascontiguousarray(kps); kps_un = np.ascontiguousarray(kps_un)
+    depth = np.ascontiguousarray(depth, np.float32)
+    ur = np.zeros(max(len(kps), 1), np.float32); dp = np.zeros(max(len(kps), 1), np.float32)
+    lib().orc_stereo_from_rgbd(_p(kps), _p(kps_un), len(kps), _p(depth), depth.shape[1], depth.shape[0], depth.shape[1],
+                               C.c_float(bf), _p(ur), _p(dp))
+    return ur[:len(kps)].copy(), dp[:len(kps)].copy()
+
+
 def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, bf, b):
     """pyrL/pyrR: lists of contiguous 2-D uint8 level planes."""
     kpsL = np.ascontiguousarray(kpsL); kpsR = np.ascontiguousarray(kpsR)

@@ -1267,6 +1267,55 @@ int orc_search_in_area(const orc_wquery *q, const uint8_t *qdesc, int nq, const 
     return nmatches;
 }
 
+static int int_cmp(const void *a, const void *b)
+{
+    const int x = *(const int *)a, y = *(const int *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:297-334). */
+void orc_distinctive_descriptors(const uint8_t *desc, const int32_t *start, int npoints,
+                                 int32_t *best_idx, int32_t *best_median)
+{
+    for (int p = 0; p < npoints; p++) {
+        const int N = start[p + 1] - start[p];
+        const uint8_t *D = desc + (size_t)start[p] * 32;
+        if (N <= 0) { best_idx[p] = -1; if (best_median) best_median[p] = -1; continue; }
+        int *dist = (int *)malloc(sizeof(int) * (size_t)N * N), *row = (int *)malloc(sizeof(int) * (size_t)N);
+        for (int i = 0; i < N; i++) {
+            dist[i * N + i] = 0;
+            for (int j = i + 1; j < N; j++) {
+                const int d = orc_hamming256(D + (size_t)i * 32, D + (size_t)j * 32);
+                dist[i * N + j] = d;
+                dist[j * N + i] = d;
+            }
+        }
+        int BestMedian = INT_MAX, BestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            memcpy(row, dist + (size_t)i * N, sizeof(int) * (size_t)N);
+            qsort(row, (size_t)N, sizeof(int), int_cmp);
+            const int median = row[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+        }
+        best_idx[p] = BestIdx;
+        if (best_median) best_median[p] = BestMedian;
+        free(dist); free(row);
+    }
+}
+
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:777-798). */
+void orc_stereo_from_rgbd(const orc_keypoint *kps, const orc_keypoint *kps_un, int n, const float *depth,
+                          int w, int h, int stride_floats, float bf, float *uright, float *out_depth)
+{
+    for (int i = 0; i < n; i++) {
+        uright[i] = -1; out_depth[i] = -1;
+        const int v = (int)kps[i].y, u = (int)kps[i].x; /* cv::Mat::at<float>(int, int) from float arguments */
+        if (u < 0 || u >= w || v < 0 || v >= h) continue; /* the reference does not check; keypoints lie inside */
+        const float d = depth[(size_t)v * stride_floats + u];
+        if (d > 0) { out_depth[i] = d; uright[i] = kps_un[i].x - bf / d; }
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774)                         */
 /* ------------------------------------------------------------------------ */

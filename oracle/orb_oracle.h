@@ -180,6 +180,15 @@ int orc_search_in_area(const orc_wquery *q, const uint8_t *qdesc, int nq, const 
                        const uint8_t *desc2, const float *uright2, int n2, const float *bounds4,
                        const float *inv_sigma2, int chi2_gate, int th_dist, int32_t *qmatch);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:297-334) for map points whose
+ * observations are desc[start[p] .. start[p+1]).  best_idx[p] relative to start[p] (-1: none). */
+void orc_distinctive_descriptors(const uint8_t *desc, const int32_t *start, int npoints,
+                                 int32_t *best_idx, int32_t *best_median);
+
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:777-798). */
+void orc_stereo_from_rgbd(const orc_keypoint *kps, const orc_keypoint *kps_un, int n, const float *depth,
+                          int w, int h, int stride_floats, float bf, float *uright, float *out_depth);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774). pyrL/pyrR: arrays of
  * nlevels interior pointers with strides. */
 int orc_stereo_matches(const orc_keypoint *kpsL, const uint8_t *descL, int nL,

@@ -38,7 +38,8 @@ EXPORTS = [
     "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync",
     "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
-    "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_in_area", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
+    "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_in_area", "orbgpu_assign_features_to_grid",
+    "orbgpu_distinctive_descriptors", "orbgpu_stereo_from_rgbd", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
 ]
 
 
@@ -101,6 +102,9 @@ def load_library():
         L.orbgpu_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, f32, f32, vp, vp, i32,
                                                       i32, i32, vp, C.POINTER(i32)]
         L.orbgpu_search_in_area.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
+        L.orbgpu_assign_features_to_grid.argtypes = [vp, vp, i32, vp, vp, vp, C.POINTER(i32)]
+        L.orbgpu_distinctive_descriptors.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.orbgpu_stereo_from_rgbd.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, f32, vp, vp]
         L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                        C.POINTER(i32)]
         L.orbgpu_stereo_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
@@ -428,6 +432,34 @@ class ORBmatcher:
                                                _p(sg), 0 if sg is None else len(sg), int(chi2_gate), th_dist, _p(qm), C.byref(n)),
                "orbgpu_search_in_area")
         return n.value, qm[:len(q)].copy()
+
+    def AssignFeaturesToGrid(self, kps_un, bounds):
+        """Frame::AssignFeaturesToGrid (src/Frame.cc:270-293): (cell_start[64*48+1], cell_index) with cell = ix*48 + iy."""
+        kps = np.ascontiguousarray(kps_un); b = np.asarray(bounds, np.float32)
+        cs = np.zeros(64 * 48 + 1, np.int32); ci = np.zeros(max(len(kps), 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_assign_features_to_grid(self._h, _p(kps), len(kps), _p(b), _p(cs), _p(ci), C.byref(n)),
+               "orbgpu_assign_features_to_grid")
+        return cs, ci[:n.value].copy()
+
+    def ComputeDistinctiveDescriptors(self, desc, start):
+        """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:262-340) for many map points at once: observations of
+        map point p are desc[start[p]:start[p+1]].  Returns (best index within the range, its median distance)."""
+        desc = np.ascontiguousarray(desc, np.uint8); start = np.ascontiguousarray(start, np.int32)
+        n = len(start) - 1
+        bi = np.zeros(max(n, 1), np.int32); bm = np.zeros(max(n, 1), np.int32)
+        _check(self._lib.orbgpu_distinctive_descriptors(self._h, _p(desc), _p(start), n, _p(bi), _p(bm)),
+               "orbgpu_distinctive_descriptors")
+        return bi[:n].copy(), bm[:n].copy()
+
+    def ComputeStereoFromRGBD(self, kps, kps_un, depth, bf):
+        """Frame::ComputeStereoFromRGBD (src/Frame.cc:777-798).  Returns (mvuRight, mvDepth)."""
+        kps = np.ascontiguousarray(kps); kps_un = np.ascontiguousarray(kps_un)
+        depth = np.ascontiguousarray(depth, np.float32)
+        ur = np.zeros(max(len(kps), 1), np.float32); dp = np.zeros(max(len(kps), 1), np.float32)
+        _check(self._lib.orbgpu_stereo_from_rgbd(self._h, _p(kps), _p(kps_un), len(kps), _p(depth), depth.shape[1], depth.shape[0],
+                                                 depth.shape[1], bf, _p(ur), _p(dp)), "orbgpu_stereo_from_rgbd")
+        return ur[:len(kps)].copy(), dp[:len(kps)].copy()
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds, vbPrevMatched, windowSize=10):
         """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""

@@ -210,4 +210,94 @@ int launch_stereo(hipStream_t st, const StereoArgs &A)
     return ORBGPU_OK;
 }
 
+// ---------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:297-334), batched: map point p
+// observes descriptors desc[start[p] .. start[p+1]); the representative is the one whose
+// median distance to all of them (itself included) is smallest, first one among equals.
+// One wave per map point, a lane per row of the distance matrix; the median of a row is its
+// k-th smallest value, k = (int)(0.5*(N-1)), found by a 9-step binary search on the value
+// (the largest v with #{d < v} <= k) with the distances recomputed in every step.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_distinctive(const uint32_t *__restrict__ desc, const int32_t *__restrict__ start, int npoints,
+                                                     int32_t *__restrict__ best_idx, int32_t *__restrict__ best_median)
+{
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= npoints) return;
+    const int b = start[p], N = start[p + 1] - b;
+    if (N <= 0) {
+        if (lane == 0) { best_idx[p] = -1; if (best_median) best_median[p] = -1; }
+        return;
+    }
+    const int k = (N - 1) >> 1;
+    const uint32_t *D = desc + (size_t)b * 8;
+    unsigned best = 0xFFFFFFFFu;  // median << 20 | row
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        const bool live = i < N;
+        uint32_t mine[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) mine[w] = D[(size_t)(live ? i : 0) * 8 + w];
+        int lo = 0;
+        for (int bit = 256; bit > 0; bit >>= 1) {
+            const int cand = lo | bit;
+            int below = 0;
+            for (int j = 0; j < N; j++) {
+                int d = 0;
+#pragma unroll
+                for (int w = 0; w < 8; w++) d += __popc(mine[w] ^ D[(size_t)j * 8 + w]);  // uniform address: scalar loads
+                below += d < cand ? 1 : 0;
+            }
+            if (below <= k) lo = cand;
+        }
+        unsigned key = live ? ((unsigned)lo << 20) | (unsigned)i : 0xFFFFFFFFu;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+        best = min(best, key);
+    }
+    if (lane == 0) {
+        best_idx[p] = (int)(best & 0xFFFFFu);
+        if (best_median) best_median[p] = (int)(best >> 20);
+    }
+}
+
+int launch_distinctive(hipStream_t st, const uint8_t *d_desc, const int32_t *d_start, int npoints, int32_t *d_best_idx,
+                       int32_t *d_best_median)
+{
+    hipLaunchKernelGGL(k_distinctive, dim3((npoints + 3) / 4), dim3(256), 0, st, (const uint32_t *)d_desc, d_start, npoints, d_best_idx,
+                       d_best_median);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:777-798): depth image lookup at the (distorted)
+// keypoint, truncated to integer pixel coordinates as cv::Mat::at<float>(float, float) does.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stereo_from_rgbd(const orbgpu_keypoint *__restrict__ kps, const orbgpu_keypoint *__restrict__ kps_un,
+                                                          int n, const float *__restrict__ depth, int w, int h, int stride_floats,
+                                                          float bf, float *__restrict__ uright, float *__restrict__ out_depth)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int v = (int)kps[i].y, u = (int)kps[i].x;
+    float d = 0.0f;
+    if (u >= 0 && u < w && v >= 0 && v < h) d = depth[(size_t)v * stride_floats + u];
+    if (d > 0) {
+        out_depth[i] = d;
+        uright[i] = __fsub_rn(kps_un[i].x, __fdiv_rn(bf, d));
+    } else {
+        out_depth[i] = -1.0f;
+        uright[i] = -1.0f;
+    }
+}
+
+int launch_stereo_from_rgbd(hipStream_t st, const orbgpu_keypoint *kps, const orbgpu_keypoint *kps_un, int n, const float *depth, int w,
+                            int h, int stride_floats, float bf, float *uright, float *out_depth)
+{
+    hipLaunchKernelGGL(k_stereo_from_rgbd, dim3((n + 255) / 256), dim3(256), 0, st, kps, kps_un, n, depth, w, h, stride_floats, bf, uright,
+                       out_depth);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
 }  // namespace orbgpu

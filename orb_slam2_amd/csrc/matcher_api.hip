@@ -13,9 +13,14 @@ namespace orbgpu {
 int launch_bruteforce(hipStream_t st, const uint8_t *d_Q, int nq, const uint8_t *d_T, int nt, int nsplit, int tchunk,
                       uint2 *part, int32_t *bi, int32_t *b1, int32_t *b2);
 int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs);
+int launch_grid_only(hipStream_t st, const MatchArgs &A);
 int launch_shift_queries(hipStream_t st, int npairs, const orbgpu_keypoint *kps, const int32_t *n, int capacity, float du,
                          float dv, float th, const ScaleTab &sc, const float *b4, orbgpu_wquery *q);
 int launch_stereo(hipStream_t st, const StereoArgs &A);
+int launch_distinctive(hipStream_t st, const uint8_t *d_desc, const int32_t *d_start, int npoints, int32_t *d_best_idx,
+                       int32_t *d_best_median);
+int launch_stereo_from_rgbd(hipStream_t st, const orbgpu_keypoint *kps, const orbgpu_keypoint *kps_un, int n, const float *depth, int w,
+                            int h, int stride_floats, float bf, float *uright, float *out_depth);
 
 struct MBuf {
     void *p = nullptr;
@@ -401,6 +406,111 @@ int orbgpu_search_in_area(orbgpu_matcher *m, const orbgpu_wquery *q, const uint8
     }
     return window_host(m, 6, q, qdesc, nq, kps2, desc2, chi2_gate ? uright2 : nullptr, n2, bounds4, nullptr, nullptr, qmatch, th_dist,
                        1.0f, 0, nmatches, nullptr, nullptr, 0, &X);
+}
+
+// Frame::AssignFeaturesToGrid (src/Frame.cc:270-293) with Frame::PosInGrid (:485-500).
+int orbgpu_assign_features_to_grid(orbgpu_matcher *m, const orbgpu_keypoint *kps, int32_t n, const float *bounds4, int32_t *cell_start,
+                                   int32_t *cell_index, int32_t *n_in_grid)
+{
+    if (!m || n < 0 || (n > 0 && (!kps || !cell_index)) || !bounds4 || !cell_start || !(bounds4[2] > bounds4[0]) ||
+        !(bounds4[3] > bounds4[1]) || n > (1 << 20)) {
+        set_error("orbgpu_assign_features_to_grid: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    const int tc = n > 0 ? n : 1;
+    int rc;
+    if ((rc = m->stage[2].ensure((size_t)tc * sizeof(orbgpu_keypoint)))) return rc;
+    if ((rc = m->stage[3].ensure((size_t)tc * 32))) return rc;
+    if ((rc = m->stage[8].ensure(64))) return rc;
+    if ((rc = m->scratch.ensure(match_scratch_ints(1, tc) * 4))) return rc;
+    if (n > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[2].p, kps, (size_t)n * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
+    int32_t hc[4] = {0, n, 0, 0};
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[8].p, hc, 16, hipMemcpyHostToDevice, st));
+    MatchArgs A;
+    memset(&A, 0, sizeof(A));
+    A.mode = 1;
+    A.nq = (const int32_t *)m->stage[8].p; A.q_cap = 1;
+    A.kps2 = (const orbgpu_keypoint *)m->stage[2].p; A.desc2 = (const uint8_t *)m->stage[3].p;  // descriptors are carried along, unused here
+    A.n2 = (const int32_t *)m->stage[8].p + 1; A.t_cap = tc;
+    A.minX = bounds4[0]; A.minY = bounds4[1]; A.maxX = bounds4[2]; A.maxY = bounds4[3];
+    A.scratch = (int32_t *)m->scratch.p;
+    if ((rc = launch_grid_only(st, A))) return rc;
+    // scratch layout of one pair (match_scratch_ints): candidates [kTopK*q_cap] | cell_start [3080] | grid records [4*t_cap] ...
+    const int32_t *d_cs = A.scratch + kTopK * 1;
+    const int32_t *d_rec = d_cs + 3080;
+    const int ncell = ORBGPU_GRID_COLS * ORBGPU_GRID_ROWS;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(cell_start, d_cs, (size_t)(ncell + 1) * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    const int ng = cell_start[ncell];
+    if (ng > 0)  // the keypoint index is the fourth word of every 16-byte grid record
+        ORBGPU_HIP_CHECK(hipMemcpy2DAsync(cell_index, 4, d_rec + 3, 16, 4, (size_t)ng, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    if (n_in_grid) *n_in_grid = ng;
+    return ORBGPU_OK;
+}
+
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:262-340), batched over map points.
+int orbgpu_distinctive_descriptors(orbgpu_matcher *m, const uint8_t *desc, const int32_t *start, int32_t npoints, int32_t *best_idx,
+                                   int32_t *best_median)
+{
+    if (!m || npoints < 0 || !start || (npoints > 0 && !best_idx) || start[0] != 0) {
+        set_error("orbgpu_distinctive_descriptors: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    for (int p = 0; p < npoints; p++)
+        if (start[p + 1] < start[p] || start[p + 1] - start[p] >= (1 << 20)) {
+            set_error("orbgpu_distinctive_descriptors: bad observation range of map point %d", p);
+            return ORBGPU_E_INVALID;
+        }
+    if (npoints == 0) return ORBGPU_OK;
+    const int32_t total = start[npoints];
+    if (total > 0 && !desc) { set_error("orbgpu_distinctive_descriptors: invalid argument"); return ORBGPU_E_INVALID; }
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    int rc;
+    if ((rc = m->stage[0].ensure((size_t)(total > 0 ? total : 1) * 32))) return rc;
+    if ((rc = m->stage[1].ensure((size_t)(npoints + 1) * 4))) return rc;
+    if ((rc = m->stage[2].ensure((size_t)npoints * 8))) return rc;
+    if (total > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, desc, (size_t)total * 32, hipMemcpyHostToDevice, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[1].p, start, (size_t)(npoints + 1) * 4, hipMemcpyHostToDevice, st));
+    int32_t *o = (int32_t *)m->stage[2].p;
+    if ((rc = launch_distinctive(st, (const uint8_t *)m->stage[0].p, (const int32_t *)m->stage[1].p, npoints, o, o + npoints))) return rc;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(best_idx, o, (size_t)npoints * 4, hipMemcpyDeviceToHost, st));
+    if (best_median) ORBGPU_HIP_CHECK(hipMemcpyAsync(best_median, o + npoints, (size_t)npoints * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    return ORBGPU_OK;
+}
+
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:777-798).
+int orbgpu_stereo_from_rgbd(orbgpu_matcher *m, const orbgpu_keypoint *kps, const orbgpu_keypoint *kps_un, int32_t n, const float *depth,
+                            int32_t w, int32_t h, int32_t stride_floats, float bf, float *uright, float *out_depth)
+{
+    if (!m || n < 0 || (n > 0 && (!kps || !kps_un || !uright || !out_depth)) || !depth || w < 1 || h < 1 || stride_floats < w) {
+        set_error("orbgpu_stereo_from_rgbd: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (n == 0) return ORBGPU_OK;
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    int rc;
+    if ((rc = m->stage[0].ensure((size_t)n * sizeof(orbgpu_keypoint)))) return rc;
+    if ((rc = m->stage[1].ensure((size_t)n * sizeof(orbgpu_keypoint)))) return rc;
+    if ((rc = m->stage[2].ensure((size_t)w * h * 4))) return rc;
+    if ((rc = m->stage[3].ensure((size_t)n * 8))) return rc;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, kps, (size_t)n * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[1].p, kps_un, (size_t)n * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
+    ORBGPU_HIP_CHECK(hipMemcpy2DAsync(m->stage[2].p, (size_t)w * 4, depth, (size_t)stride_floats * 4, (size_t)w * 4, (size_t)h,
+                                      hipMemcpyHostToDevice, st));
+    float *o = (float *)m->stage[3].p;
+    if ((rc = launch_stereo_from_rgbd(st, (const orbgpu_keypoint *)m->stage[0].p, (const orbgpu_keypoint *)m->stage[1].p, n,
+                                      (const float *)m->stage[2].p, w, h, w, bf, o, o + n)))
+        return rc;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(uright, o, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(out_depth, o + n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    return ORBGPU_OK;
 }
 
 int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1, const uint8_t *desc1, int32_t n1,

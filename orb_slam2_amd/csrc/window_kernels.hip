@@ -860,6 +860,14 @@ int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
     return ORBGPU_OK;
 }
 
+// The keypoint grid of one frame alone (Frame::AssignFeaturesToGrid).
+int launch_grid_only(hipStream_t st, const MatchArgs &A)
+{
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(1024), 0, st, A);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
 int launch_shift_queries(hipStream_t st, int npairs, const orbgpu_keypoint *kps, const int32_t *n, int capacity, float du,
                          float dv, float th, const ScaleTab &sc, const float *b4, orbgpu_wquery *q)
 {

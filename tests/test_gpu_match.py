@@ -240,6 +240,42 @@ def test_search_in_area(matcher, oracle, frames, th, chi2, stereo, th_dist):
         assert len(np.unique(hits)) < len(hits)  # keypoints shared between queries
 
 
+def test_assign_features_to_grid(matcher, oracle, frames):
+    k2 = frames[1][0].copy()
+    k2["x"][:5] = [-3.0, 700.0, 10.0, 639.9, 0.0]  # outside / on the rim of the grid
+    cs, ci = matcher.AssignFeaturesToGrid(k2, _bounds())
+    rcs, rci = oracle.grid_build(k2.view(oracle.KEYPOINT_DTYPE), _bounds())
+    assert np.array_equal(cs, rcs) and np.array_equal(ci, rci)
+    assert cs[-1] == len(ci) and len(ci) < len(k2)
+
+
+def test_distinctive_descriptors(matcher, oracle):
+    rng = np.random.default_rng(11)
+    sizes = [1, 2, 3, 7, 0, 64, 65, 130, 5, 4, 16] + rng.integers(1, 40, 300).tolist()
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    base = synth.descriptors(len(sizes), 3)
+    desc = np.zeros((start[-1], 32), np.uint8)
+    for p, n in enumerate(sizes):  # observations of a point = its descriptor with a few bits flipped (ties are common)
+        flips = (rng.random((n, 256)) < 0.08)
+        desc[start[p]:start[p + 1]] = base[p] ^ np.packbits(flips, axis=1)
+    bi, bm = matcher.ComputeDistinctiveDescriptors(desc, start)
+    rbi, rbm = oracle.distinctive_descriptors(desc, start)
+    assert np.array_equal(bi, rbi) and np.array_equal(bm, rbm)
+    assert bi[4] == -1 and bi[0] == 0
+
+
+def test_stereo_from_rgbd(matcher, oracle, frames):
+    k = frames[0][0]
+    ku = k.copy(); ku["x"] += 0.25
+    rng = np.random.default_rng(12)
+    depth = rng.uniform(0.3, 8.0, (480, 640)).astype(np.float32)
+    depth[rng.random(depth.shape) < 0.2] = 0.0
+    ur, dp = matcher.ComputeStereoFromRGBD(k, ku, depth, 40.0)
+    rur, rdp = oracle.stereo_from_rgbd(k.view(oracle.KEYPOINT_DTYPE), ku.view(oracle.KEYPOINT_DTYPE), depth, 40.0)
+    assert np.array_equal(ur, rur) and np.array_equal(dp, rdp)
+    assert (dp > 0).sum() > 500 and (dp < 0).sum() > 50
+
+
 def test_search_by_bow_rejects_bad_segments(matcher):
     from orb_slam2_amd import api
     q = np.zeros(1, api.WQUERY_DTYPE); q["flags"] = 1; q["minLevel"] = 3

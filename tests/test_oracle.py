@@ -653,6 +653,38 @@ def test_keyframe_projection_overload_is_mode_keyframe(oracle, two_frames):
     assert n == cnt and cnt > 50 and np.array_equal(assign, ref)
 
 
+def test_distinctive_descriptors_against_numpy(oracle):
+    """src/MapPoint.cc:297-334 with numpy: full distance matrix, sorted rows, element int(0.5*(N-1)), first minimum."""
+    rng = np.random.default_rng(21)
+    sizes = [1, 2, 5, 8, 33, 0, 12]
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    desc = rng.integers(0, 256, (start[-1], 32), dtype=np.uint8)
+    desc[8:16] = desc[8] ^ (rng.random((8, 32)) < 0.05).astype(np.uint8)  # near-duplicates: ties in the medians
+    bi, bm = oracle.distinctive_descriptors(desc, start)
+    for p, n in enumerate(sizes):
+        if n == 0:
+            assert bi[p] == -1
+            continue
+        D = desc[start[p]:start[p + 1]]
+        dist = np.unpackbits(D[:, None, :] ^ D[None, :, :], axis=2).sum(axis=2)
+        med = np.sort(dist, axis=1)[:, int(0.5 * (n - 1))]
+        assert bi[p] == int(np.argmin(med)) and bm[p] == med.min()
+
+
+def test_stereo_from_rgbd_against_numpy(oracle, two_frames):
+    k = two_frames[0][0]
+    ku = k.copy(); ku["x"] -= 0.5
+    rng = np.random.default_rng(22)
+    depth = rng.uniform(0.0, 5.0, (240, 320)).astype(np.float32)
+    depth[depth < 1.0] = 0.0
+    ur, dp = oracle.stereo_from_rgbd(k, ku, depth, 30.0)
+    d = depth[k["y"].astype(np.int32), k["x"].astype(np.int32)]
+    ok = d > 0
+    assert np.array_equal(dp, np.where(ok, d, np.float32(-1)))
+    ref = np.where(ok, ku["x"] - np.float32(30.0) / np.where(ok, d, np.float32(1)), np.float32(-1)).astype(np.float32)
+    assert np.array_equal(ur, ref)
+
+
 def test_search_for_initialization_against_python(oracle, two_frames):
     (k1, d1), (k2, d2) = two_frames
     b = np.array([0, 0, 320, 240], np.float32)
