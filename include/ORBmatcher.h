@@ -8,8 +8,8 @@
  * pose projection that turns a map point into an image window is host glue
  * outside the descriptor path.  The methods here therefore take the arrays
  * those objects hold (keypoints, descriptors, mvuRight, "has a map point"
- * flags) plus one window query per map point; INTEGRATION.md shows the
- * few-line adapters that give the Frame-based overloads back.
+ * flags) plus one window query per map point; the Frame-based overloads become
+ * few-line adapters that keep their pose arithmetic and fill those arrays.
  */
 #ifndef ORBGPU_ORBMATCHER_H
 #define ORBGPU_ORBMATCHER_H

@@ -157,7 +157,7 @@ def test_unsupported_sizes_report_errors():
 
 
 def test_4k_frame_8000_features(oracle):
-    """BASELINE config 4 geometry (3840x2160, 8000 features): one frame, bit-exact against the oracle."""
+    """4K geometry (3840x2160, 8000 features): one frame, bit-exact against the oracle."""
     img = synth.sequence(3840, 2160, 1, seed=4, n_shapes=3000)[0]
     ex = _mk(3840, 2160, 8000)
     oe = oracle.Extractor(8000)

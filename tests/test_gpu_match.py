@@ -321,7 +321,7 @@ def test_stereo_matches(oracle):
 
 
 def test_stereo_matches_kitti_geometry(oracle):
-    """BASELINE config 2 geometry: 1241x376, 2000 features per side, KITTI bf / baseline."""
+    """KITTI stereo geometry: 1241x376, 2000 features per side, KITTI bf / baseline."""
     from orb_slam2_amd.api import ORBextractor, ORBmatcher
     L, R, disp = synth.stereo_pair(1241, 376, seed=2)
     exL = ORBextractor(2000, 1.2, 8, 20, 7, max_width=1241, max_height=376)
@@ -344,7 +344,7 @@ def test_stereo_matches_kitti_geometry(oracle):
 
 
 def test_bruteforce_100k_properties(matcher):
-    """BASELINE config 5 size: 100k x 100k.  Checked through size-independent properties
+    """Large brute-force case: 100k x 100k.  Checked through size-independent properties
     (planted partner recovery, self-match, distance symmetry on a sample)."""
     from orb_slam2_amd.api import ORBmatcher
     Q = synth.descriptors(100000, 5)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Side measurements for the other BASELINE.json configs (not the bench.py contract line):
+"""Side measurements for the other workload configurations (not the bench.py contract line):
 KITTI / EuRoC stereo frames through the host API, 4K batches device-resident, and the
 100k x 100k brute-force Hamming scan.  Prints one JSON object per config."""
 import json
