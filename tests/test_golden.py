@@ -41,6 +41,62 @@ def test_oracle_reproduces_match_goldens(oracle):
     assert np.array_equal(bi, g["bf_idx"]) and np.array_equal(b1, g["bf_d1"]) and np.array_equal(b2, g["bf_d2"])
 
 
+def _match2(run_bow, run_tri, run_area, run_dd):
+    e = _load("extract_320x240.npz"); g = _load("match2_320x240.npz")
+    b = np.array([0, 0, 320, 240], np.float32)
+    qi = g["bow_qi"]
+    n, assign, qm = run_bow(g["bow_q"], e["desc0"][qi], e["kps1"], e["desc1"], g["bow_ss"], g["bow_si"])
+    assert n == int(g["bow_n"]) and np.array_equal(assign, g["bow_assign"]) and np.array_equal(qm, g["bow_qm"])
+    sc = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    n, qm = run_tri(g["bow_q"], e["desc0"][qi], e["kps1"], e["desc1"], g["bow_ss"], g["bow_si"], g["tri_has1"], g["tri_F"])
+    assert n == int(g["tri_n"]) and np.array_equal(qm, g["tri_qm"])
+    n, qm = run_area(g["area_q"], e["desc0"], e["kps1"], e["desc1"], b, g["area_ur"])
+    assert n == int(g["area_n"]) and np.array_equal(qm, g["area_qm"])
+    bi, bm = run_dd(g["dd_obs"], g["dd_start"])
+    assert np.array_equal(bi, g["dd_idx"]) and np.array_equal(bm, g["dd_med"])
+    del sc
+
+
+def _scale_tables(oracle):
+    sc = oracle.tables(oracle.make_params(500))["scale"]
+    return sc, (sc * sc).astype(np.float32), (1.0 / (sc * sc)).astype(np.float32)
+
+
+def test_oracle_reproduces_match2_goldens(oracle):
+    sc, s2, inv = _scale_tables(oracle)
+    _match2(lambda q, qd, k, d, ss, si: oracle.search_by_bow(q, qd, k, d, ss, si, None, 50, 0.75, True),
+            lambda q, qd, k, d, ss, si, has, F: oracle.search_for_triangulation(q, qd, k, d, None, ss, si, has, F, 150.0, 100.0, sc,
+                                                                               s2, False, True),
+            lambda q, qd, k, d, b, ur: oracle.search_in_area(q, qd, k, d, b, ur, inv, True, 50),
+            oracle.distinctive_descriptors)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_match2_goldens(oracle):
+    from orb_slam2_amd import api
+    sc, s2, inv = _scale_tables(oracle)
+    m = api.ORBmatcher(0.75, True)
+    lib, C = api.load_library(), api.C
+
+    def bow(q, qd, k, d, ss, si):
+        q = np.ascontiguousarray(q); qd = np.ascontiguousarray(qd); k = np.ascontiguousarray(k); d = np.ascontiguousarray(d)
+        a = np.zeros(len(k), np.int32); qm = np.zeros(len(q), np.int32); n = C.c_int32()
+        assert lib.orbgpu_search_by_bow(m._h, api._p(q), api._p(qd), len(q), api._p(k), api._p(d), len(k), api._p(ss), api._p(si),
+                                        len(ss) - 1, None, 50, 0.75, 1, api._p(a), api._p(qm), C.byref(n)) == 0
+        return n.value, a, qm
+
+    def tri(q, qd, k, d, ss, si, has, F):
+        q = np.ascontiguousarray(q); qd = np.ascontiguousarray(qd); k = np.ascontiguousarray(k); d = np.ascontiguousarray(d)
+        F = np.ascontiguousarray(F, np.float32).reshape(9)
+        qm = np.zeros(len(q), np.int32); n = C.c_int32()
+        assert lib.orbgpu_search_for_triangulation(m._h, api._p(q), api._p(qd), len(q), api._p(k), api._p(d), None, len(k), api._p(ss),
+                                                   api._p(si), len(ss) - 1, api._p(has), api._p(F), 150.0, 100.0, api._p(sc),
+                                                   api._p(s2), len(sc), 0, 1, api._p(qm), C.byref(n)) == 0
+        return n.value, qm
+
+    _match2(bow, tri, lambda q, qd, k, d, b, ur: m.SearchInArea(q, qd, k, d, b, ur, inv, True, 50), m.ComputeDistinctiveDescriptors)
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_extraction_goldens():
     from orb_slam2_amd.api import ORBextractor

@@ -62,4 +62,34 @@ T[7] = Q[3]
 bi, b1, b2 = O.bruteforce(Q, T)
 fix.update(bf_Q=Q, bf_T=T, bf_idx=bi, bf_d1=b1, bf_d2=b2)
 np.savez_compressed(os.path.join(out, "match_320x240.npz"), **fix)
+# 4. BoW-guided matchers, the independent window search and the distinctive-descriptor choice on the frames of (1);
+#    the FeatureVectors are the three leading descriptor bits (stand-in for the vocabulary)
+k0, d0, k1, d1 = res[0][0], res[0][1], res[1][0], res[1][1]
+fv0 = {int(n): np.nonzero((d0[:, 0] >> 5) == n)[0].tolist() for n in np.unique(d0[:, 0] >> 5)}
+fv1 = {int(n): np.nonzero((d1[:, 0] >> 5) == n)[0].tolist() for n in np.unique(d1[:, 0] >> 5)}
+rng = np.random.default_rng(7)
+valid0 = (rng.random(len(k0)) < 0.8)
+qi, qs, ss, si = api.bow_segments(fv0, fv1, valid0)
+qb = np.zeros(len(qi), O.WQUERY_DTYPE)
+qb["u"] = k0["x"][qi]; qb["v"] = k0["y"][qi]; qb["angle"] = k0["angle"][qi]; qb["minLevel"] = qs; qb["flags"] = 1
+n, assign, qm = O.search_by_bow(qb, d0[qi], k1, d1, ss, si, None, 50, 0.75, True)
+fix2 = dict(bow_q=qb, bow_qi=qi, bow_ss=ss, bow_si=si, bow_n=np.int32(n), bow_assign=assign, bow_qm=qm)
+t = np.array([2.0, 1.0], np.float32) / np.float32(np.sqrt(5.0))
+F12 = np.array([[0, 0, t[1]], [0, 0, -t[0]], [-t[1], t[0], 0]], np.float32)
+has1 = (rng.random(len(k1)) < 0.2).astype(np.uint8)
+sigma2 = (sc * sc).astype(np.float32)
+n, qm = O.search_for_triangulation(qb, d0[qi], k1, d1, None, ss, si, has1, F12, 150.0, 100.0, sc, sigma2, False, True)
+fix2.update(tri_F=F12, tri_has1=has1, tri_n=np.int32(n), tri_qm=qm)
+qa = api.shift_queries(k0, -2.0, -1.0, 4.0, sc, b)
+qa["minLevel"] = k0["octave"] - 1; qa["maxLevel"] = k0["octave"]; qa["ur"] = qa["u"] - 3.0
+ur1 = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 3.5, -1.0).astype(np.float32)
+inv_s2 = (1.0 / (sc * sc)).astype(np.float32)
+n, qm = O.search_in_area(qa.view(O.WQUERY_DTYPE), d0, k1, d1, b, ur1, inv_s2, True, 50)
+fix2.update(area_q=qa, area_ur=ur1, area_n=np.int32(n), area_qm=qm)
+sizes = rng.integers(1, 30, 60)
+start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+obs = np.concatenate([d0[rng.integers(0, len(d0))] ^ np.packbits(rng.random((s_, 256)) < 0.08, axis=1) for s_ in sizes])
+bi, bm = O.distinctive_descriptors(obs, start)
+fix2.update(dd_obs=obs, dd_start=start, dd_idx=bi, dd_med=bm)
+np.savez_compressed(os.path.join(out, "match2_320x240.npz"), **fix2)
 print("golden fixtures written to", out)
