@@ -239,6 +239,16 @@ public:
         return rc;
     }
 
+    // Frame::UndistortKeyPoints (src/Frame.cc:517-558): K4 = {fx, fy, cx, cy}, dist5 = {k1, k2, p1, p2, k3}.
+    int UndistortKeyPoints(const std::vector<orbcv::KeyPoint> &keys, const float K4[4], const float dist5[5],
+                           std::vector<orbcv::KeyPoint> &keysUn)
+    {
+        keysUn = keys;
+        if (!handle_ || keys.empty()) return 0;
+        return check(orbgpu_undistort_keypoints(handle_, reinterpret_cast<const orbgpu_keypoint *>(keys.data()), (int32_t)keys.size(), K4,
+                                                dist5, reinterpret_cast<orbgpu_keypoint *>(keysUn.data())));
+    }
+
     // Frame::ComputeStereoFromRGBD (src/Frame.cc:777-798): depth = CV_32F image rows of strideFloats floats.
     int ComputeStereoFromRGBD(const std::vector<orbcv::KeyPoint> &keys, const std::vector<orbcv::KeyPoint> &keysUn, const float *depth,
                               int w, int h, int strideFloats, float bf, std::vector<float> &mvuRight, std::vector<float> &mvDepth)

@@ -311,6 +311,13 @@ int orbgpu_stereo_from_rgbd(orbgpu_matcher *m, const orbgpu_keypoint *kps, const
                             int32_t n, const float *depth, int32_t w, int32_t h, int32_t stride_floats,
                             float bf, float *uright, float *out_depth);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:517-558): cv::undistortPoints with R = I and
+ * P = K.  K4 = {fx, fy, cx, cy}, dist5 = {k1, k2, p1, p2, k3} (mDistCoef; k3 = 0 when
+ * the calibration has four coefficients).  Copies the keypoints when k1 == 0, as the
+ * reference does.  Only pt.x / pt.y change. */
+int orbgpu_undistort_keypoints(orbgpu_matcher *m, const orbgpu_keypoint *kps, int32_t n, const float *K4,
+                               const float *dist5, orbgpu_keypoint *kps_un);
+
 /* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:422-571).
  * prev_matched_xy[2*n1] in/out (vbPrevMatched), matches12[n1] out. */
 int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *kps1,

@@ -329,6 +329,13 @@ def stereo_from_rgbd(kps, kps_un, depth, bf):
     return ur[:len(kps)].copy(), dp[:len(kps)].copy()
 
 
+def undistort_keypoints(kps, K4, D5):
+    kps = np.ascontiguousarray(kps); out = np.zeros_like(kps)
+    K = np.ascontiguousarray(K4, np.float32); D = np.ascontiguousarray(D5, np.float32)
+    lib().orc_undistort_keypoints(_p(kps), len(kps), _p(K), _p(D), _p(out))
+    return out
+
+
 def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, bf, b):
     """pyrL/pyrR: lists of contiguous 2-D uint8 level planes."""
     kpsL = np.ascontiguousarray(kpsL); kpsR = np.ascontiguousarray(kpsR)

@@ -1316,6 +1316,38 @@ void orc_stereo_from_rgbd(const orc_keypoint *kps, const orc_keypoint *kps_un, i
     }
 }
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:517-558); cv::undistortPoints [OpenCV-knowledge]. */
+void orc_undistort_keypoints(const orc_keypoint *kps, int n, const float *K4, const float *D5, orc_keypoint *out)
+{
+    if (D5[0] == 0.0f) { /* :519-523 */
+        for (int i = 0; i < n; i++) out[i] = kps[i];
+        return;
+    }
+    const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    const double k[12] = {D5[0], D5[1], D5[2], D5[3], D5[4], 0, 0, 0, 0, 0, 0, 0};
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double RR[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}}; /* P * R with R = I, P = K */
+    for (int i = 0; i < n; i++) {
+        double x = kps[i].x, y = kps[i].y;
+        const double x0 = x = (x - cx) * ifx;
+        const double y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+        const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+        const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        out[i] = kps[i];
+        out[i].x = (float)(xx * ww);
+        out[i].y = (float)(yy * ww);
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774)                         */
 /* ------------------------------------------------------------------------ */

@@ -189,6 +189,10 @@ void orc_distinctive_descriptors(const uint8_t *desc, const int32_t *start, int 
 void orc_stereo_from_rgbd(const orc_keypoint *kps, const orc_keypoint *kps_un, int n, const float *depth,
                           int w, int h, int stride_floats, float bf, float *uright, float *out_depth);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:517-558) = cv::undistortPoints(pts, K, D, I, K): OpenCV's
+ * cvUndistortPoints restated (double precision, five iterations).  K4 = fx, fy, cx, cy; D5 = k1, k2, p1, p2, k3. */
+void orc_undistort_keypoints(const orc_keypoint *kps, int n, const float *K4, const float *D5, orc_keypoint *out);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774). pyrL/pyrR: arrays of
  * nlevels interior pointers with strides. */
 int orc_stereo_matches(const orc_keypoint *kpsL, const uint8_t *descL, int nL,

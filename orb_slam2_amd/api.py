@@ -39,7 +39,7 @@ EXPORTS = [
     "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
     "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_in_area", "orbgpu_assign_features_to_grid",
-    "orbgpu_distinctive_descriptors", "orbgpu_stereo_from_rgbd", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
+    "orbgpu_distinctive_descriptors", "orbgpu_stereo_from_rgbd", "orbgpu_undistort_keypoints", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
 ]
 
 
@@ -105,6 +105,7 @@ def load_library():
         L.orbgpu_assign_features_to_grid.argtypes = [vp, vp, i32, vp, vp, vp, C.POINTER(i32)]
         L.orbgpu_distinctive_descriptors.argtypes = [vp, vp, vp, i32, vp, vp]
         L.orbgpu_stereo_from_rgbd.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, f32, vp, vp]
+        L.orbgpu_undistort_keypoints.argtypes = [vp, vp, i32, vp, vp, vp]
         L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                        C.POINTER(i32)]
         L.orbgpu_stereo_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
@@ -441,6 +442,13 @@ class ORBmatcher:
         _check(self._lib.orbgpu_assign_features_to_grid(self._h, _p(kps), len(kps), _p(b), _p(cs), _p(ci), C.byref(n)),
                "orbgpu_assign_features_to_grid")
         return cs, ci[:n.value].copy()
+
+    def UndistortKeyPoints(self, kps, K4, dist5):
+        """Frame::UndistortKeyPoints (src/Frame.cc:517-558); K4 = (fx, fy, cx, cy), dist5 = (k1, k2, p1, p2, k3)."""
+        kps = np.ascontiguousarray(kps); out = np.zeros_like(kps)
+        K = np.ascontiguousarray(K4, np.float32); D = np.ascontiguousarray(dist5, np.float32)
+        _check(self._lib.orbgpu_undistort_keypoints(self._h, _p(kps), len(kps), _p(K), _p(D), _p(out)), "orbgpu_undistort_keypoints")
+        return out
 
     def ComputeDistinctiveDescriptors(self, desc, start):
         """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:262-340) for many map points at once: observations of

@@ -19,6 +19,7 @@ int launch_shift_queries(hipStream_t st, int npairs, const orbgpu_keypoint *kps,
 int launch_stereo(hipStream_t st, const StereoArgs &A);
 int launch_distinctive(hipStream_t st, const uint8_t *d_desc, const int32_t *d_start, int npoints, int32_t *d_best_idx,
                        int32_t *d_best_median);
+int launch_undistort(hipStream_t st, const orbgpu_keypoint *kps, int n, const float *K4, const float *D5, orbgpu_keypoint *out);
 int launch_stereo_from_rgbd(hipStream_t st, const orbgpu_keypoint *kps, const orbgpu_keypoint *kps_un, int n, const float *depth, int w,
                             int h, int stride_floats, float bf, float *uright, float *out_depth);
 
@@ -509,6 +510,31 @@ int orbgpu_stereo_from_rgbd(orbgpu_matcher *m, const orbgpu_keypoint *kps, const
         return rc;
     ORBGPU_HIP_CHECK(hipMemcpyAsync(uright, o, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_CHECK(hipMemcpyAsync(out_depth, o + n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    return ORBGPU_OK;
+}
+
+// Frame::UndistortKeyPoints (src/Frame.cc:517-558).
+int orbgpu_undistort_keypoints(orbgpu_matcher *m, const orbgpu_keypoint *kps, int32_t n, const float *K4, const float *dist5,
+                               orbgpu_keypoint *kps_un)
+{
+    if (!m || n < 0 || (n > 0 && (!kps || !kps_un)) || !K4 || !dist5 || K4[0] == 0.0f || K4[1] == 0.0f) {
+        set_error("orbgpu_undistort_keypoints: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (n == 0) return ORBGPU_OK;
+    if (dist5[0] == 0.0f) {  // :519-523: no distortion, plain copy
+        if (kps_un != kps) memcpy(kps_un, kps, (size_t)n * sizeof(orbgpu_keypoint));
+        return ORBGPU_OK;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    int rc;
+    if ((rc = m->stage[0].ensure((size_t)n * sizeof(orbgpu_keypoint)))) return rc;
+    if ((rc = m->stage[1].ensure((size_t)n * sizeof(orbgpu_keypoint)))) return rc;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, kps, (size_t)n * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
+    if ((rc = launch_undistort(st, (const orbgpu_keypoint *)m->stage[0].p, n, K4, dist5, (orbgpu_keypoint *)m->stage[1].p))) return rc;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(kps_un, m->stage[1].p, (size_t)n * sizeof(orbgpu_keypoint), hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
     return ORBGPU_OK;
 }

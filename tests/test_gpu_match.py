@@ -264,6 +264,20 @@ def test_distinctive_descriptors(matcher, oracle):
     assert bi[4] == -1 and bi[0] == 0
 
 
+def test_undistort_keypoints(matcher, oracle, frames):
+    k = frames[0][0]
+    K4 = [517.306408, 516.469215, 318.643040, 255.313989]        # Examples/Monocular/TUM1.yaml:9-12
+    D5 = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]    # TUM1.yaml:14-18
+    got = matcher.UndistortKeyPoints(k, K4, D5)
+    ref = oracle.undistort_keypoints(k.view(oracle.KEYPOINT_DTYPE), K4, D5).view(k.dtype)
+    # double-precision evaluation on both sides; allow the last float bit (tolerance 1e-4 px), observed identical
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-4 and np.abs(got["y"] - ref["y"]).max() <= 1e-4
+    assert np.array_equal(got["octave"], k["octave"]) and np.array_equal(got["angle"], k["angle"])
+    assert np.abs(got["x"] - k["x"]).max() > 1.0   # the distortion moves points
+    same = matcher.UndistortKeyPoints(k, K4, [0, 0, 0, 0, 0])
+    assert np.array_equal(same, k)
+
+
 def test_stereo_from_rgbd(matcher, oracle, frames):
     k = frames[0][0]
     ku = k.copy(); ku["x"] += 0.25

@@ -671,6 +671,23 @@ def test_distinctive_descriptors_against_numpy(oracle):
         assert bi[p] == int(np.argmin(med)) and bm[p] == med.min()
 
 
+def test_undistort_keypoints_inverts_the_distortion_model(oracle, two_frames):
+    """Property check of the restated cv::undistortPoints: pushing the result through the forward radial + tangential
+    model must give the original pixel back (the five iterations leave well under 0.01 px here)."""
+    k = two_frames[0][0]
+    fx, fy, cx, cy = 258.6, 258.2, 159.3, 127.6                       # TUM1.yaml:9-12 scaled to 320x240
+    k1, k2, p1, p2, k3 = 0.262383, -0.953104, -0.005358, 0.002628, 1.163314
+    un = oracle.undistort_keypoints(k, [fx, fy, cx, cy], [k1, k2, p1, p2, k3])
+    x = (un["x"].astype(np.float64) - cx) / fx; y = (un["y"].astype(np.float64) - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    assert np.abs(xd * fx + cx - k["x"]).max() < 0.01 and np.abs(yd * fy + cy - k["y"]).max() < 0.01
+    assert np.abs(un["x"] - k["x"]).max() > 0.5
+    assert np.array_equal(oracle.undistort_keypoints(k, [fx, fy, cx, cy], [0, 0, 0, 0, 0]), k)
+
+
 def test_stereo_from_rgbd_against_numpy(oracle, two_frames):
     k = two_frames[0][0]
     ku = k.copy(); ku["x"] -= 0.5
