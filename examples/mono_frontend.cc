@@ -3,17 +3,20 @@
 // ORB_SLAM2::ORBextractor and matches them with
 // ORB_SLAM2::ORBmatcher::SearchForInitialization -- the calls Tracking makes
 // (src/Tracking.cc:160-168, 738-748 of the reference) -- and prints a summary.
+// With a vocabulary text file as second argument it also runs Frame::ComputeBoW
+// (src/Frame.cc:503-510) on the first frame through ORB_SLAM2::ORBVocabulary.
 //
 // Build: g++ -std=c++14 -Iinclude examples/mono_frontend.cc -Lorb_slam2_amd -lorbgpu -Wl,-rpath,$PWD/orb_slam2_amd
 #include <cstdio>
 #include <cstdlib>
 
+#include "ORBVocabulary.h"
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s frames.raw\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s frames.raw [vocabulary.txt]\n", argv[0]); return 2; }
     FILE *f = std::fopen(argv[1], "rb");
     if (!f) { std::perror("open"); return 2; }
     int wh[2];
@@ -44,5 +47,20 @@ int main(int argc, char **argv)
     for (size_t i = 0; i < matches12.size(); i++) sum = (sum * 31 + (matches12[i] + 2)) % 1000000007L;
     std::printf("keypoints %zu %zu pyramid0 %dx%d matches %d checksum %ld\n", keys[0].size(), keys[1].size(),
                 extractor.mvImagePyramid[0].cols, extractor.mvImagePyramid[0].rows, n, sum);
+    if (argc > 2) {
+        ORB_SLAM2::ORBVocabulary voc;
+        if (!voc.loadFromTextFile(argv[2])) { std::fprintf(stderr, "vocabulary: %s\n", voc.LastError().c_str()); return 1; }
+        DBoW2::BowVector bow;
+        DBoW2::FeatureVector fv;
+        voc.transform(desc[0], bow, fv, 2);
+        long fsum = 0;
+        size_t nfeat = 0;
+        for (DBoW2::FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it)
+            for (size_t i = 0; i < it->second.size(); i++, nfeat++) fsum = (fsum * 31 + it->first * 7 + it->second[i]) % 1000000007L;
+        double total = 0;
+        for (DBoW2::BowVector::const_iterator it = bow.begin(); it != bow.end(); ++it) total += it->second;
+        std::printf("words %u bow %zu sum %.17g nodes %zu features %zu checksum %ld\n", voc.size(), bow.size(), total, fv.size(), nfeat,
+                    fsum);
+    }
     return 0;
 }

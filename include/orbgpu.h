@@ -337,6 +337,77 @@ int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extrac
                         int32_t nR, float bf, float b, float *uRight, float *depth,
                         int32_t *nvalid);
 
+/* ---- ORBVocabulary (DBoW2) ---------------------------------------------- */
+/* Citations in this block are relative to Thirdparty/DBoW2/DBoW2/ of the reference. */
+
+typedef struct orbgpu_vocabulary orbgpu_vocabulary;
+
+/* WeightingType and ScoringType (BowVector.h:36-55). */
+#define ORBGPU_WEIGHT_TF_IDF 0
+#define ORBGPU_WEIGHT_TF 1
+#define ORBGPU_WEIGHT_IDF 2
+#define ORBGPU_WEIGHT_BINARY 3
+#define ORBGPU_SCORE_L1_NORM 0
+#define ORBGPU_SCORE_L2_NORM 1
+#define ORBGPU_SCORE_CHI_SQUARE 2
+#define ORBGPU_SCORE_KL 3
+#define ORBGPU_SCORE_BHATTACHARYYA 4
+#define ORBGPU_SCORE_DOT_PRODUCT 5
+
+/* A vocabulary tree from the arrays TemplatedVocabulary::loadFromTextFile reads
+ * (TemplatedVocabulary.h:1338-1424): node i+1 (i = 0 .. n_nodes-1, file order; node 0
+ * is the root) has parent[i], is_leaf[i], desc[i*32 ..], weight[i]; children keep
+ * file order and words are numbered in file order of the leaves.  k, L, scoring and
+ * weighting are the header fields, accepted in the ranges of :1359.  Unlike the
+ * reference, which does not check, a tree in which a parent is not an earlier
+ * node, a leaf has children or an inner node has none is refused
+ * (ORBGPU_E_INVALID); more than 32 children per node: ORBGPU_E_UNSUPPORTED. */
+int orbgpu_vocabulary_create(int32_t device, int32_t k, int32_t L, int32_t scoring, int32_t weighting,
+                             int32_t n_nodes, const int32_t *parent, const uint8_t *is_leaf,
+                             const uint8_t *desc, const double *weight, orbgpu_vocabulary **out);
+/* ORBVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1424; called at
+ * src/System.cc:77).  Blank lines add no node: the reference's `while(!f.eof())`
+ * loop turns the empty line after the final newline into one more child of the
+ * root with an uninitialised descriptor; that node is not reproduced. */
+int orbgpu_vocabulary_load_text(int32_t device, const char *path, orbgpu_vocabulary **out);
+void orbgpu_vocabulary_destroy(orbgpu_vocabulary *v);
+int orbgpu_vocabulary_set_stream(orbgpu_vocabulary *v, void *hip_stream);
+int orbgpu_vocabulary_sync(orbgpu_vocabulary *v);
+/* getBranchingFactor, getDepthLevels, getScoringType, getWeightingType, node count
+ * without the root, size() = number of words (TemplatedVocabulary.h:100-223).  Any
+ * pointer may be NULL. */
+int orbgpu_vocabulary_info(const orbgpu_vocabulary *v, int32_t *k, int32_t *L, int32_t *scoring,
+                           int32_t *weighting, int32_t *n_nodes, int32_t *n_words);
+
+/* TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
+ * (TemplatedVocabulary.h:1127-1194) = Frame::ComputeBoW / KeyFrame::ComputeBoW
+ * (src/Frame.cc:503-510, src/KeyFrame.cc:65-76; levelsup = 4) for n descriptors
+ * of 32 bytes.  Per feature (either may be NULL): word_ids[n] and node_ids[n],
+ * the node at level L - levelsup on the feature's path (0 when that level is
+ * <= 0; where the leaf lies above that level the reference leaves the id unset
+ * and this library reports the leaf).  BowVector: ascending bow_ids[*n_bow] with
+ * bow_vals, accumulated and normalised in the order std::map gives
+ * (BowVector.cpp:34-84), so the doubles are bit-identical.  FeatureVector:
+ * ascending fv_nodes[*n_fv]; node j lists the features
+ * fv_feat[fv_start[j] .. fv_start[j+1]) in ascending order (FeatureVector.cpp:31-45).
+ * Features whose word has weight 0 are in neither.  Capacities: n entries each,
+ * fv_start n+1.  n <= 16384. */
+int orbgpu_vocabulary_transform(orbgpu_vocabulary *v, const uint8_t *desc, int32_t n, int32_t levelsup,
+                                int32_t *word_ids, int32_t *node_ids, int32_t *bow_ids,
+                                double *bow_vals, int32_t *n_bow, int32_t *fv_nodes,
+                                int32_t *fv_start, int32_t *fv_feat, int32_t *n_fv);
+
+/* Same for nsets descriptor sets resident on the device, asynchronous on the
+ * handle's stream: set s has min(d_counts[s], capacity) descriptors at
+ * d_desc + s*capacity*32 (the layout orbgpu_extract_batch_device writes); every
+ * output uses the stride `capacity` per set, d_fv_start capacity+1. */
+int orbgpu_vocabulary_transform_batch_device(orbgpu_vocabulary *v, const uint8_t *d_desc,
+                                             const int32_t *d_counts, int32_t nsets, int32_t capacity,
+                                             int32_t levelsup, int32_t *d_word_ids, int32_t *d_node_ids,
+                                             int32_t *d_bow_ids, double *d_bow_vals, int32_t *d_n_bow,
+                                             int32_t *d_fv_nodes, int32_t *d_fv_start,
+                                             int32_t *d_fv_feat, int32_t *d_n_fv);
+
 #ifdef __cplusplus
 }
 #endif

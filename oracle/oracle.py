@@ -352,3 +352,25 @@ def stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale, inv_scale, bf, b
     n = lib().orc_stereo_matches(_p(kpsL), _p(descL), len(kpsL), _p(kpsR), _p(descR), len(kpsR), PL, PR, _p(ws), _p(hs),
                                  _p(sL), _p(sR), nl, _p(sc), _p(isc), C.c_float(bf), C.c_float(b), _p(uR), _p(dep))
     return n, uR[:len(kpsL)].copy(), dep[:len(kpsL)].copy()
+
+
+def voc_transform(voc, desc, levelsup=4):
+    """voc: dict with L, scoring, weighting, parent, is_leaf, desc, weight (arrays in vocabulary-file order).
+    Returns word_id[n], node_id[n], (bow_ids, bow_vals), (fv_nodes, fv_start, fv_feat)."""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(desc)
+    parent = np.ascontiguousarray(voc["parent"], np.int32); leaf = np.ascontiguousarray(voc["is_leaf"], np.uint8)
+    nd = np.ascontiguousarray(voc["desc"], np.uint8); wt = np.ascontiguousarray(voc["weight"], np.float64)
+    m = max(n, 1)
+    wid = np.zeros(m, np.int32); nid = np.zeros(m, np.int32)
+    bi = np.zeros(m, np.int32); bv = np.zeros(m, np.float64); nb = C.c_int32(0)
+    fn = np.zeros(m, np.int32); fs = np.zeros(m + 1, np.int32); ff = np.zeros(m, np.int32); nf = C.c_int32(0)
+    f = lib().orc_voc_transform
+    f.restype = C.c_int
+    rc = f(int(voc["L"]), int(voc["scoring"]), int(voc["weighting"]), len(parent), _p(parent), _p(leaf), _p(nd), _p(wt),
+           _p(desc), n, int(levelsup), _p(wid), _p(nid), _p(bi), _p(bv), C.byref(nb), _p(fn), _p(fs), _p(ff), C.byref(nf))
+    if rc:
+        raise ValueError("inconsistent vocabulary tree")
+    nb = nb.value; nf = nf.value
+    return wid[:n].copy(), nid[:n].copy(), (bi[:nb].copy(), bv[:nb].copy()), (fn[:nf].copy(), fs[:nf + 1].copy(), ff[:fs[nf]].copy())
+

@@ -1349,6 +1349,113 @@ void orc_undistort_keypoints(const orc_keypoint *kps, int n, const float *K4, co
 }
 
 /* ------------------------------------------------------------------------ */
+/* DBoW2 vocabulary transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h)    */
+/* ------------------------------------------------------------------------ */
+static int int32_cmp(const void *a, const void *b)
+{
+    const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+typedef struct { int32_t node, feat; } node_feat;
+static int node_feat_cmp(const void *a, const void *b)
+{
+    const node_feat *x = (const node_feat *)a, *y = (const node_feat *)b;
+    if (x->node != y->node) return x->node < y->node ? -1 : 1;
+    return x->feat < y->feat ? -1 : (x->feat > y->feat ? 1 : 0);
+}
+
+int orc_voc_transform(int L, int scoring, int weighting, int n_nodes, const int32_t *parent,
+                      const uint8_t *is_leaf, const uint8_t *node_desc, const double *weight,
+                      const uint8_t *feat_desc, int n, int levelsup, int32_t *word_id,
+                      int32_t *node_id, int32_t *bow_ids, double *bow_vals, int32_t *n_bow,
+                      int32_t *fv_nodes, int32_t *fv_start, int32_t *fv_feat, int32_t *n_fv)
+{
+    *n_bow = 0; *n_fv = 0; fv_start[0] = 0; /* v.clear(); fv.clear(); :1131-1132 */
+    /* m_nodes[pid].children.push_back(nid) in file order (:1385-1392); words in file order of the leaves (:1408-1415) */
+    int32_t *cstart = (int32_t *)calloc((size_t)n_nodes + 2, sizeof(int32_t));
+    int32_t *child = (int32_t *)malloc(((size_t)n_nodes + 1) * sizeof(int32_t));
+    int32_t *cur = (int32_t *)malloc(((size_t)n_nodes + 1) * sizeof(int32_t));
+    int32_t *wid = (int32_t *)malloc(((size_t)n_nodes + 1) * sizeof(int32_t));
+    int rc = 0, n_words = 0;
+    for (int i = 0; i < n_nodes; i++) {
+        if (parent[i] < 0 || parent[i] > i) { rc = -1; break; }
+        cstart[parent[i] + 1]++;
+    }
+    if (!rc) {
+        for (int j = 0; j <= n_nodes; j++) { cstart[j + 1] += cstart[j]; }
+        for (int j = 0; j <= n_nodes; j++) cur[j] = cstart[j];
+        for (int i = 0; i < n_nodes; i++) child[cur[parent[i]]++] = i + 1;
+        wid[0] = -1;
+        for (int i = 0; i < n_nodes; i++) {
+            wid[i + 1] = is_leaf[i] ? n_words++ : -1;
+            if ((cstart[i + 2] - cstart[i + 1] == 0) != (is_leaf[i] != 0)) rc = -1;
+        }
+    }
+    if (rc || n_words == 0) { /* empty(): :1134 */
+        free(cstart); free(child); free(cur); free(wid);
+        return rc;
+    }
+    double *acc = (double *)calloc((size_t)n_words, sizeof(double));
+    uint8_t *seen = (uint8_t *)calloc((size_t)n_words, 1);
+    node_feat *nf = (node_feat *)malloc(((size_t)n + 1) * sizeof(node_feat));
+    int nkept = 0, nb = 0;
+    const int nid_level = L - levelsup; /* :1226 */
+    const int tf = weighting == 0 || weighting == 1; /* TF_IDF, TF (BowVector.h:36-42) */
+    for (int f = 0; f < n; f++) {
+        const uint8_t *d = feat_desc + (size_t)f * 32;
+        int final_id = 0, level = 0, nid = nid_level <= 0 ? 0 : -1; /* :1227-1230 */
+        do { /* :1232-1254 */
+            ++level;
+            const int32_t *ch = child + cstart[final_id];
+            const int nch = cstart[final_id + 1] - cstart[final_id];
+            final_id = ch[0];
+            int best_d = orc_hamming256(d, node_desc + (size_t)(final_id - 1) * 32);
+            for (int c = 1; c < nch; c++) {
+                const int dd = orc_hamming256(d, node_desc + (size_t)(ch[c] - 1) * 32);
+                if (dd < best_d) { best_d = dd; final_id = ch[c]; }
+            }
+            if (level == nid_level) nid = final_id;
+        } while (cstart[final_id + 1] - cstart[final_id] > 0);
+        /* the reference leaves *nid unset when the leaf lies above nid_level (an uninitialised local of
+         * :1151); this restatement reports the leaf itself there */
+        if (nid < 0) nid = final_id;
+        const int w_id = wid[final_id];
+        const double w = weight[final_id - 1];
+        word_id[f] = w_id; node_id[f] = nid;
+        if (w > 0) { /* :1157, :1185 */
+            if (!seen[w_id]) { seen[w_id] = 1; bow_ids[nb++] = w_id; acc[w_id] = w; } /* insert */
+            else if (tf) acc[w_id] += w;                                              /* addWeight; addIfNotExist keeps the first */
+            nf[nkept].node = nid; nf[nkept].feat = f; nkept++;
+        }
+    }
+    qsort(bow_ids, (size_t)nb, sizeof(int32_t), int32_cmp); /* std::map iteration order */
+    for (int j = 0; j < nb; j++) bow_vals[j] = acc[bow_ids[j]];
+    /* mustNormalize (ScoringObject.h:74-89): every scoring but DOT_PRODUCT; L2 norm only for L2_NORM */
+    const int must = scoring != 5, l2 = scoring == 1;
+    if (tf && nb > 0 && !must) { /* :1164-1170 */
+        const double nd = (double)nb;
+        for (int j = 0; j < nb; j++) bow_vals[j] /= nd;
+    }
+    if (must) { /* BowVector::normalize, BowVector.cpp:62-84 */
+        double norm = 0.0;
+        if (!l2) { for (int j = 0; j < nb; j++) norm += fabs(bow_vals[j]); }
+        else { for (int j = 0; j < nb; j++) norm += bow_vals[j] * bow_vals[j]; norm = sqrt(norm); }
+        if (norm > 0.0) for (int j = 0; j < nb; j++) bow_vals[j] /= norm;
+    }
+    *n_bow = nb;
+    qsort(nf, (size_t)nkept, sizeof(node_feat), node_feat_cmp);
+    int nn = 0;
+    for (int j = 0; j < nkept; j++) {
+        if (j == 0 || nf[j].node != nf[j - 1].node) { fv_nodes[nn] = nf[j].node; fv_start[nn] = j; nn++; }
+        fv_feat[j] = nf[j].feat;
+    }
+    fv_start[nn] = nkept;
+    *n_fv = nn;
+    free(acc); free(seen); free(nf); free(cstart); free(child); free(cur); free(wid);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774)                         */
 /* ------------------------------------------------------------------------ */
 typedef struct { int d, i; } dist_idx;

@@ -193,6 +193,26 @@ void orc_stereo_from_rgbd(const orc_keypoint *kps, const orc_keypoint *kps_un, i
  * cvUndistortPoints restated (double precision, five iterations).  K4 = fx, fy, cx, cy; D5 = k1, k2, p1, p2, k3. */
 void orc_undistort_keypoints(const orc_keypoint *kps, int n, const float *K4, const float *D5, orc_keypoint *out);
 
+/* DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(features, BowVector, FeatureVector,
+ * levelsup) (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1194) with the per-feature tree
+ * descent of :1217-1259 and FORB::distance (Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101); this is
+ * Frame::ComputeBoW (src/Frame.cc:503-510, levelsup = 4).
+ * The vocabulary is given as the arrays loadFromTextFile (:1338-1424) reads: node i+1 (i = 0 ..
+ * n_nodes-1, in file order; node 0 is the root) has parent[i], is_leaf[i], node_desc[i*32..],
+ * weight[i]; words are numbered in file order of the leaves.  scoring / weighting are the
+ * enumerators of BowVector.h:36-55.
+ * Outputs: word_id[n], node_id[n] per feature (node at level L - levelsup, 0 if that is <= 0);
+ * BowVector as ascending bow_ids[*n_bow] / bow_vals (std::map order, BowVector.cpp:34-84);
+ * FeatureVector as ascending fv_nodes[*n_fv] with features fv_feat[fv_start[j] .. fv_start[j+1])
+ * in insertion (= ascending feature) order (FeatureVector.cpp:31-45).  Returns 0, or -1 on an
+ * inconsistent tree (a parent that is not an earlier node, a leaf with children, an inner node
+ * without). */
+int orc_voc_transform(int L, int scoring, int weighting, int n_nodes, const int32_t *parent,
+                      const uint8_t *is_leaf, const uint8_t *node_desc, const double *weight,
+                      const uint8_t *feat_desc, int n, int levelsup, int32_t *word_id,
+                      int32_t *node_id, int32_t *bow_ids, double *bow_vals, int32_t *n_bow,
+                      int32_t *fv_nodes, int32_t *fv_start, int32_t *fv_feat, int32_t *n_fv);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774). pyrL/pyrR: arrays of
  * nlevels interior pointers with strides. */
 int orc_stereo_matches(const orc_keypoint *kpsL, const uint8_t *descL, int nL,

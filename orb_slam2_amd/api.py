@@ -40,6 +40,8 @@ EXPORTS = [
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
     "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_in_area", "orbgpu_assign_features_to_grid",
     "orbgpu_distinctive_descriptors", "orbgpu_stereo_from_rgbd", "orbgpu_undistort_keypoints", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
+    "orbgpu_vocabulary_create", "orbgpu_vocabulary_load_text", "orbgpu_vocabulary_destroy", "orbgpu_vocabulary_set_stream",
+    "orbgpu_vocabulary_sync", "orbgpu_vocabulary_info", "orbgpu_vocabulary_transform", "orbgpu_vocabulary_transform_batch_device",
 ]
 
 
@@ -109,6 +111,15 @@ def load_library():
         L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                        C.POINTER(i32)]
         L.orbgpu_stereo_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
+        L.orbgpu_vocabulary_create.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]
+        L.orbgpu_vocabulary_load_text.argtypes = [i32, C.c_char_p, C.POINTER(vp)]
+        L.orbgpu_vocabulary_destroy.argtypes = [vp]
+        L.orbgpu_vocabulary_destroy.restype = None
+        L.orbgpu_vocabulary_set_stream.argtypes = [vp, vp]
+        L.orbgpu_vocabulary_sync.argtypes = [vp]
+        L.orbgpu_vocabulary_info.argtypes = [vp] + [C.POINTER(i32)] * 6
+        L.orbgpu_vocabulary_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, C.POINTER(i32), vp, vp, vp, C.POINTER(i32)]
+        L.orbgpu_vocabulary_transform_batch_device.argtypes = [vp, vp, vp, i32, i32, i32] + [vp] * 9
         _lib = L
     return _lib
 
@@ -525,3 +536,106 @@ def shift_queries(kps_last, du, dv, th, scale, bounds):
     inside = ~((q["u"] < bounds[0]) | (q["u"] > bounds[2]) | (q["v"] < bounds[1]) | (q["v"] > bounds[3]))
     q["flags"] = np.where(inside, 3, 0)
     return q
+
+
+class ORBVocabulary:
+    """DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> as ORB-SLAM2 uses it (include/ORBVocabulary.h:31-32):
+    loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424) and
+    transform(features, BowVector, FeatureVector, levelsup) (:1127-1194) on the device."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._device = device
+        self._h = C.c_void_p(None)
+
+    def _replace(self, h):
+        if self._h:
+            self._lib.orbgpu_vocabulary_destroy(self._h)
+        self._h = h
+
+    def loadFromTextFile(self, filename):
+        """Returns True on success like the reference; the reason of a failure is in LastError()."""
+        h = C.c_void_p(None)
+        rc = self._lib.orbgpu_vocabulary_load_text(self._device, os.fsencode(filename), C.byref(h))
+        if rc != 0:
+            return False
+        self._replace(h)
+        return True
+
+    def LastError(self):
+        return self._lib.orbgpu_last_error().decode("utf-8", "replace")
+
+    @classmethod
+    def from_arrays(cls, k, L, parent, is_leaf, desc, weight, scoring=0, weighting=0, device=0):
+        """Vocabulary from node arrays in file order (node i+1 <- parent[i], is_leaf[i], desc[i], weight[i])."""
+        self = cls(device)
+        parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
+        if not (len(parent) == len(is_leaf) == len(desc) == len(weight)) or (len(desc) and desc.shape[1:] != (32,)):
+            raise ValueError("parent, is_leaf, desc [n,32] and weight must describe the same nodes")
+        h = C.c_void_p(None)
+        _check(self._lib.orbgpu_vocabulary_create(device, k, L, scoring, weighting, len(parent), _p(parent), _p(is_leaf), _p(desc),
+                                                  _p(weight), C.byref(h)), "orbgpu_vocabulary_create")
+        self._h = h
+        return self
+
+    def __del__(self):
+        try:
+            self._replace(None)
+        except Exception:
+            pass
+
+    def _info(self):
+        v = [C.c_int32(0) for _ in range(6)]
+        _check(self._lib.orbgpu_vocabulary_info(self._h, *[C.byref(x) for x in v]), "orbgpu_vocabulary_info")
+        return [x.value for x in v]
+
+    def empty(self):
+        return (not self._h) or self._info()[5] == 0
+
+    def size(self):
+        return self._info()[5] if self._h else 0
+
+    def getBranchingFactor(self):
+        return self._info()[0]
+
+    def getDepthLevels(self):
+        return self._info()[1]
+
+    def getScoringType(self):
+        return self._info()[2]
+
+    def getWeightingType(self):
+        return self._info()[3]
+
+    def transform_arrays(self, descriptors, levelsup=4):
+        """word_id[n], node_id[n], (bow_ids, bow_vals), (fv_nodes, fv_start, fv_feat): the containers as sorted arrays."""
+        if not self._h:
+            raise OrbGpuError("the vocabulary has not been loaded")
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d); m = max(n, 1)
+        wid = np.zeros(m, np.int32); nid = np.zeros(m, np.int32)
+        bi = np.zeros(m, np.int32); bv = np.zeros(m, np.float64); nb = C.c_int32(0)
+        fn = np.zeros(m, np.int32); fs = np.zeros(m + 1, np.int32); ff = np.zeros(m, np.int32); nf = C.c_int32(0)
+        _check(self._lib.orbgpu_vocabulary_transform(self._h, _p(d), n, levelsup, _p(wid), _p(nid), _p(bi), _p(bv), C.byref(nb),
+                                                     _p(fn), _p(fs), _p(ff), C.byref(nf)), "orbgpu_vocabulary_transform")
+        nb = nb.value; nf = nf.value
+        return wid[:n], nid[:n], (bi[:nb], bv[:nb]), (fn[:nf], fs[:nf + 1], ff[:fs[nf]])
+
+    def transform(self, descriptors, levelsup=4):
+        """(BowVector, FeatureVector) as the reference's maps: {WordId: value}, {NodeId: [feature indices]}."""
+        _, _, (bi, bv), (fn, fs, ff) = self.transform_arrays(descriptors, levelsup)
+        bow = {int(i): float(v) for i, v in zip(bi, bv)}
+        fv = {int(nd): [int(x) for x in ff[fs[j]:fs[j + 1]]] for j, nd in enumerate(fn)}
+        return bow, fv
+
+    def transform_batch_device(self, d_desc_ptr, d_counts_ptr, nsets, capacity, levelsup, out_ptrs):
+        """Asynchronous device variant; out_ptrs = the nine device pointers of orbgpu_vocabulary_transform_batch_device."""
+        _check(self._lib.orbgpu_vocabulary_transform_batch_device(self._h, d_desc_ptr, d_counts_ptr, nsets, capacity, levelsup,
+                                                                  *out_ptrs), "orbgpu_vocabulary_transform_batch_device")
+
+    def set_stream(self, stream_ptr):
+        _check(self._lib.orbgpu_vocabulary_set_stream(self._h, stream_ptr), "orbgpu_vocabulary_set_stream")
+
+    def sync(self):
+        _check(self._lib.orbgpu_vocabulary_sync(self._h), "orbgpu_vocabulary_sync")

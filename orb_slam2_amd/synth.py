@@ -81,3 +81,74 @@ def planted(Q, seed, flip=0.1):
     bits = np.unpackbits(Q[perm], axis=1)
     bits ^= (rng.random(bits.shape) < flip).astype(np.uint8)
     return np.packbits(bits, axis=1), perm
+
+
+def vocabulary(k=10, L=3, seed=0, ragged=True, stop_frac=0.03, scoring=0, weighting=0):
+    """Seeded stand-in for a DBoW2 ORB vocabulary (the real ORBvoc.txt is not available): a k-ary tree of
+    depth <= L in the node order DBoW2 creates and saves (the children of a node are numbered
+    contiguously, then each child is expanded depth first).  Child descriptors are noisy copies of
+    their parent (fewer flipped bits deeper down), some siblings are exact duplicates (ties), some
+    words have weight 0 (stopped).  With `ragged`, nodes have 2..k children and some stop above L.
+    Returns a dict of arrays over nodes 1..n in file order: parent, is_leaf, desc [n,32], weight."""
+    rng = np.random.default_rng(seed)
+    parent, leaf, desc, weight = [], [], [], []
+
+    def expand(pid, pdesc, level):
+        nch = int(rng.integers(2, k + 1)) if ragged else k
+        first = len(parent) + 1
+        flip = 0.5 if level == 1 else 0.25 / level
+        ch = []
+        for c in range(nch):
+            if c > 0 and rng.random() < 0.08:
+                d = ch[int(rng.integers(0, c))].copy()
+            else:
+                bits = np.unpackbits(pdesc)
+                bits ^= (rng.random(256) < flip).astype(np.uint8)
+                d = np.packbits(bits)
+            ch.append(d)
+            parent.append(pid); leaf.append(1); desc.append(d); weight.append(0.0)
+        for c in range(nch):
+            nid = first + c
+            if level < L and not (ragged and level >= 1 and rng.random() < 0.12):
+                leaf[nid - 1] = 0
+                expand(nid, ch[c], level + 1)
+            else:
+                weight[nid - 1] = 0.0 if rng.random() < stop_frac else float(rng.uniform(0.05, 9.0))
+
+    expand(0, np.zeros(32, np.uint8), 1)
+    return {"k": k, "L": L, "scoring": scoring, "weighting": weighting,
+            "parent": np.asarray(parent, np.int32), "is_leaf": np.asarray(leaf, np.uint8),
+            "desc": np.asarray(desc, np.uint8).reshape(-1, 32), "weight": np.asarray(weight, np.float64)}
+
+
+def vocabulary_full(k=10, L=6, seed=0, scoring=0, weighting=0):
+    """Complete k-ary tree of depth L (the shape of the stock ORB vocabulary: k = 10, L = 6, 1.1 M nodes), built
+    level by level with numpy; nodes are numbered breadth first (every parent precedes its children)."""
+    rng = np.random.default_rng(seed)
+    parent, leaf, desc = [], [], []
+    prev_ids = np.zeros(1, np.int64); prev_desc = np.zeros((1, 32), np.uint8)
+    nxt = 1
+    for level in range(1, L + 1):
+        n = len(prev_ids) * k
+        ids = np.arange(nxt, nxt + n)
+        flips = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        for _ in range(min(level - 1, 3)):  # 50 %, 25 %, 12.5 %, 6.25 % of the bits differ from the parent
+            flips &= rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        d = np.repeat(prev_desc, k, axis=0) ^ flips
+        parent.append(np.repeat(prev_ids, k)); leaf.append(np.full(n, level == L, np.uint8)); desc.append(d)
+        prev_ids, prev_desc, nxt = ids, d, nxt + n
+    nwords = len(prev_ids)
+    weight = np.zeros(nxt - 1, np.float64)
+    weight[-nwords:] = rng.uniform(0.05, 9.0, nwords)
+    return {"k": k, "L": L, "scoring": scoring, "weighting": weighting, "parent": np.concatenate(parent).astype(np.int32),
+            "is_leaf": np.concatenate(leaf), "desc": np.concatenate(desc), "weight": weight}
+
+
+def save_vocabulary_text(path, voc, trailing_newline=True):
+    """Write `voc` in the text format of DBoW2's saveToTextFile / loadFromTextFile ("k L  scoring weighting",
+    then one line per node: parent, leaf flag, 32 descriptor bytes, weight)."""
+    lines = ["%d %d  %d %d" % (voc["k"], voc["L"], voc["scoring"], voc["weighting"])]
+    for p, l, d, w in zip(voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"]):
+        lines.append("%d %d %s  %s" % (p, l, " ".join(str(int(b)) for b in d), repr(float(w))))
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + ("\n" if trailing_newline else ""))

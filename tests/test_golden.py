@@ -135,3 +135,34 @@ def test_gpu_reproduces_match_goldens():
     assert n == int(g["init_n"]) and np.array_equal(m12, g["init_m12"]) and np.array_equal(po, g["init_prev"])
     bi, b1, b2 = m9.BruteForce(g["bf_Q"], g["bf_T"])
     assert np.array_equal(bi, g["bf_idx"]) and np.array_equal(b1, g["bf_d1"]) and np.array_equal(b2, g["bf_d2"])
+
+
+def _bow_golden(transform):
+    """transform(voc dict, features, levelsup) -> word ids, node ids, (bow ids, values), (fv nodes, starts, features)."""
+    g = _load("bow_k8_L3.npz")
+    for tag in "abc":
+        weighting, scoring, levelsup = (int(x) for x in g["cfg_" + tag])
+        voc = dict(k=int(g["k"]), L=int(g["L"]), parent=g["parent"], is_leaf=g["is_leaf"], desc=g["node_desc"], weight=g["weight"],
+                   weighting=weighting, scoring=scoring)
+        wid, nid, (bi, bv), (fn, fs, ff) = transform(voc, g["feat"], levelsup)
+        assert np.array_equal(wid, g["wid_" + tag]) and np.array_equal(nid, g["nid_" + tag])
+        assert np.array_equal(bi, g["bi_" + tag])
+        assert np.array_equal(np.asarray(bv).view(np.uint64), g["bv_" + tag].view(np.uint64))
+        assert np.array_equal(fn, g["fn_" + tag]) and np.array_equal(fs, g["fs_" + tag]) and np.array_equal(ff, g["ff_" + tag])
+        assert len(bi) > 30 and len(fn) >= 1
+
+
+def test_oracle_reproduces_vocabulary_goldens(oracle):
+    _bow_golden(oracle.voc_transform)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_vocabulary_goldens():
+    from orb_slam2_amd.api import ORBVocabulary
+
+    def transform(voc, feat, levelsup):
+        v = ORBVocabulary.from_arrays(voc["k"], voc["L"], voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"],
+                                      scoring=voc["scoring"], weighting=voc["weighting"])
+        return v.transform_arrays(feat, levelsup)
+
+    _bow_golden(transform)

@@ -25,13 +25,15 @@ def test_cpp_shim_headers_compile_and_link():
 
 @pytest.mark.gpu
 def test_cpp_driver_matches_python(tmp_path):
-    from orb_slam2_amd.api import ORBextractor, ORBmatcher
+    from orb_slam2_amd.api import ORBextractor, ORBmatcher, ORBVocabulary
     seq = synth.sequence(640, 480, 2, seed=1)
     raw = tmp_path / "frames.raw"
     with open(raw, "wb") as f:
         f.write(np.array([640, 480], np.int32).tobytes())
         f.write(seq.tobytes())
-    out = subprocess.run([EXE, str(raw)], capture_output=True, text=True, timeout=120)
+    voc = synth.vocabulary(10, 3, seed=12, ragged=False)
+    synth.save_vocabulary_text(str(tmp_path / "voc.txt"), voc)
+    out = subprocess.run([EXE, str(raw), str(tmp_path / "voc.txt")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     tok = out.stdout.split()
     ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480)
@@ -45,3 +47,17 @@ def test_cpp_driver_matches_python(tmp_path):
     assert tok[1:3] == [str(len(k0)), str(len(k1))]
     assert tok[4] == "640x480"
     assert int(tok[6]) == n and int(tok[8]) == s
+    # second line: Frame::ComputeBoW on the first frame through ORB_SLAM2::ORBVocabulary
+    v = ORBVocabulary()
+    assert v.loadFromTextFile(str(tmp_path / "voc.txt"))
+    bow, fv = v.transform(d0, 2)
+    fsum = 0
+    for node in sorted(fv):
+        for i in fv[node]:
+            fsum = (fsum * 31 + node * 7 + i) % 1000000007
+    total = 0.0
+    for w in sorted(bow):
+        total += bow[w]
+    t2 = out.stdout.splitlines()[1].split()
+    assert t2[0] == "words" and int(t2[1]) == v.size() and int(t2[3]) == len(bow)
+    assert float(t2[5]) == total and int(t2[7]) == len(fv) and int(t2[11]) == fsum

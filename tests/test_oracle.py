@@ -755,3 +755,120 @@ def test_stereo_matches_on_synthetic_pair(oracle):
     d_true = disp[np.clip(kL["y"][ok].astype(int), 0, 299)]
     assert np.mean(np.abs(d_est - d_true) < 1.5) > 0.8
     assert (uR[~ok] == -1).all() and (dep[~ok] == -1).all()
+
+
+# ---- DBoW2 vocabulary transform -------------------------------------------------------------------
+
+def _py_voc_transform(voc, desc, levelsup):
+    """TemplatedVocabulary::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1259) on Python dicts:
+    dict insertion/+= for addWeight / addIfNotExist, sorted() for std::map order, float = IEEE double."""
+    import math
+    children, words = {}, {}
+    for i, p in enumerate(voc["parent"]):
+        children.setdefault(int(p), []).append(i + 1)
+    for i, l in enumerate(voc["is_leaf"]):
+        if l:
+            words[i + 1] = len(words)
+    L, weighting, scoring = voc["L"], voc["weighting"], voc["scoring"]
+    tf = weighting in (0, 1)
+    must, l2 = scoring != 5, scoring == 1
+    bow, fv, wids, nids = {}, {}, [], []
+    for f, d in enumerate(desc):
+        node, level = 0, 0
+        nid = 0 if L - levelsup <= 0 else None
+        while True:
+            level += 1
+            ch = children[node]
+            dist = [int(np.unpackbits(d ^ voc["desc"][c - 1]).sum()) for c in ch]
+            node = ch[dist.index(min(dist))]  # first minimum: `d < best_d` is strict
+            if level == L - levelsup:
+                nid = node
+            if node not in children:
+                break
+        if nid is None:
+            nid = node
+        w = float(voc["weight"][node - 1])
+        wids.append(words[node]); nids.append(nid)
+        if w > 0:
+            if words[node] not in bow:
+                bow[words[node]] = w
+            elif tf:
+                bow[words[node]] += w
+            fv.setdefault(nid, []).append(f)
+    ids = sorted(bow)
+    vals = [bow[i] for i in ids]
+    if tf and ids and not must:
+        vals = [v / float(len(ids)) for v in vals]
+    if must:
+        norm = 0.0
+        for v in vals:
+            norm += v * v if l2 else abs(v)
+        if l2:
+            norm = math.sqrt(norm)
+        if norm > 0.0:
+            vals = [v / norm for v in vals]
+    return wids, nids, ids, vals, fv
+
+
+def _voc_features(voc, n, seed, flip=0.02):
+    """Features near the words (so that words repeat), a few exact copies of inner nodes and a few random ones."""
+    rng = np.random.default_rng(seed)
+    leaves = voc["desc"][voc["is_leaf"] == 1]
+    pick = rng.integers(0, max(len(leaves) // 3, 1), n)  # a third of the words: several features per word
+    d = leaves[pick].copy()
+    bits = np.unpackbits(d, axis=1)
+    bits ^= (rng.random(bits.shape) < flip).astype(np.uint8)
+    d = np.packbits(bits, axis=1)
+    d[::17] = voc["desc"][rng.integers(0, len(voc["desc"]), len(d[::17]))]
+    d[::29] = rng.integers(0, 256, (len(d[::29]), 32), dtype=np.uint8)
+    return d
+
+
+@pytest.mark.parametrize("k,L,ragged,weighting,scoring,levelsup,n", [
+    (10, 3, True, 0, 0, 1, 300), (10, 3, False, 0, 0, 2, 300), (4, 4, True, 1, 1, 2, 200), (6, 3, True, 2, 0, 4, 200),
+    (5, 3, True, 3, 5, 1, 150), (9, 2, True, 0, 5, 1, 150), (3, 5, True, 0, 2, 0, 120)])
+def test_voc_transform_against_python_restatement(oracle, k, L, ragged, weighting, scoring, levelsup, n):
+    voc = synth.vocabulary(k, L, seed=k * 10 + L, ragged=ragged, scoring=scoring, weighting=weighting)
+    desc = _voc_features(voc, n, seed=n + k)
+    wid, nid, (bi, bv), (fn, fs, ff) = oracle.voc_transform(voc, desc, levelsup)
+    pw, pn, pids, pvals, pfv = _py_voc_transform(voc, desc, levelsup)
+    assert list(wid) == pw and list(nid) == pn
+    assert list(bi) == pids
+    assert np.array_equal(bv.view(np.uint64), np.asarray(pvals, np.float64).view(np.uint64))  # bit-identical doubles
+    assert list(fn) == sorted(pfv)
+    for j, node in enumerate(fn):
+        assert list(ff[fs[j]:fs[j + 1]]) == pfv[int(node)]
+    kept = sum(len(v) for v in pfv.values())
+    assert fs[-1] == kept and 0 < kept <= n
+    if weighting in (0, 1):
+        assert max(len(v) for v in pfv.values()) >= 3  # several features per node / word
+    if scoring == 0:
+        assert abs(bv.sum() - 1.0) < 1e-12
+
+
+def test_voc_transform_edge_cases(oracle):
+    voc = synth.vocabulary(10, 3, seed=5)
+    # no features
+    wid, nid, (bi, bv), (fn, fs, ff) = oracle.voc_transform(voc, np.zeros((0, 32), np.uint8), 1)
+    assert len(wid) == 0 and len(bi) == 0 and len(fn) == 0 and list(fs) == [0]
+    # every word stopped: both containers stay empty
+    stopped = dict(voc); stopped["weight"] = np.zeros_like(voc["weight"])
+    d = _voc_features(voc, 50, 1)
+    wid, nid, (bi, bv), (fn, fs, ff) = oracle.voc_transform(stopped, d, 1)
+    assert len(wid) == 50 and len(bi) == 0 and len(fn) == 0
+    # levelsup >= L: every feature hangs off the root (node 0)
+    wid, nid, (bi, bv), (fn, fs, ff) = oracle.voc_transform(voc, d, 3)
+    assert (nid == 0).all() and list(fn) == [0]
+    # an exact copy of a leaf descriptor reaches a word at distance 0 from it
+    leaf = int(np.flatnonzero(voc["is_leaf"])[7])
+    wid, nid, _, _ = oracle.voc_transform(voc, voc["desc"][leaf][None], 0)
+    words = np.cumsum(voc["is_leaf"]) - 1
+    reached = int(np.flatnonzero((words == wid[0]) & (voc["is_leaf"] == 1))[0])
+    assert nid[0] == reached + 1  # levelsup 0 at full depth: the node is the leaf itself, or a shallower leaf
+    # inconsistent trees are refused
+    bad = dict(voc); bad["parent"] = voc["parent"].copy(); bad["parent"][3] = 50
+    with pytest.raises(ValueError):
+        oracle.voc_transform(bad, d, 1)
+    bad = dict(voc); bad["is_leaf"] = voc["is_leaf"].copy(); bad["is_leaf"][0] ^= 1
+    with pytest.raises(ValueError):
+        oracle.voc_transform(bad, d, 1)

@@ -79,8 +79,35 @@ def brute(n=100000):
                       "hbm_GBps": (64.0 * n + 12.0 * n) / dt / 1e9}), flush=True)
 
 
+def bow(B=512, nfeat=1000):
+    """Frame::ComputeBoW for B frames of TUM-sized features against a 10^6-word tree (shape of the stock vocabulary)."""
+    voc = synth.vocabulary_full(10, 6, seed=1)
+    v = api.ORBVocabulary.from_arrays(10, 6, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    seq = synth.sequence(640, 480, 8, seed=1)
+    ex = api.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=B)
+    cap = ex.max_keypoints
+    d = torch.from_numpy(np.ascontiguousarray(np.tile(seq, (B // 8, 1, 1)))).to(dev)
+    k = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev); ds = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    c = torch.zeros(B, dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d.data_ptr(), B, 640, 480, 640, 640 * 480, k.data_ptr(), ds.data_ptr(), cap, c.data_ptr())
+    ex.sync()
+    i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
+    outs = [i32(B, cap), i32(B, cap), i32(B, cap), torch.zeros((B, cap), dtype=torch.float64, device=dev), i32(B), i32(B, cap),
+            i32(B, cap + 1), i32(B, cap), i32(B)]
+
+    def step():
+        v.transform_batch_device(ds.data_ptr(), c.data_ptr(), B, cap, 4, [t.data_ptr() for t in outs])
+        v.sync()
+    dt = timed(step, 10)
+    nf = float(c.float().sum().item())
+    print(json.dumps({"config": "ComputeBoW, %d frames x %d features, vocabulary k=10 L=6 (%d nodes)" % (B, nfeat, len(voc["parent"])),
+                      "ms": dt * 1e3, "us_per_frame": dt * 1e6 / B, "features_per_s": nf / dt,
+                      "words_per_frame": float(outs[4].float().mean().item()), "nodes_per_frame": float(outs[8].float().mean().item())}),
+          flush=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kitti", "euroc", "4k", "bf"]
+    which = sys.argv[1:] or ["kitti", "euroc", "4k", "bf", "bow"]
     if "kitti" in which:
         stereo("KITTI 1241x376 stereo, 2000 features/side + ComputeStereoMatches", 1241, 376, 2000, 386.1448, 718.856, 2)
     if "euroc" in which:
@@ -89,3 +116,5 @@ if __name__ == "__main__":
         batch_4k()
     if "bf" in which:
         brute()
+    if "bow" in which:
+        bow()

@@ -7,7 +7,7 @@ ORACLE's behaviour: a later change to the oracle or to the synthetic image
 generator that alters any output shows up as a fixture mismatch.  Images are
 stored too, so the fixtures do not depend on numpy's random streams.
 
-Usage: python tools/make_golden.py
+Usage: python tools/make_golden.py [bow]     ("bow": only the vocabulary fixture)
 """
 import os
 import sys
@@ -21,6 +21,24 @@ from orb_slam2_amd import api, synth  # noqa: E402
 
 out = os.path.join(ROOT, "tests", "golden")
 os.makedirs(out, exist_ok=True)
+
+# 0. vocabulary transform (the DBoW2 vocabulary file is not available: a seeded stand-in tree, stored in the fixture)
+voc = synth.vocabulary(8, 3, seed=21)
+rng = np.random.default_rng(22)
+leaves = voc["desc"][voc["is_leaf"] == 1]
+feat = leaves[rng.integers(0, len(leaves) // 3, 400)] ^ np.packbits(rng.random((400, 256)) < 0.02, axis=1)
+feat[::29] = rng.integers(0, 256, (len(feat[::29]), 32), dtype=np.uint8)
+fixb = dict(k=np.int32(8), L=np.int32(3), parent=voc["parent"], is_leaf=voc["is_leaf"], node_desc=voc["desc"],
+            weight=voc["weight"], feat=feat)
+for tag, (weighting, scoring, levelsup) in {"a": (0, 0, 1), "b": (1, 1, 2), "c": (3, 5, 0)}.items():
+    v = dict(voc, weighting=weighting, scoring=scoring)
+    wid, nid, (bi, bv), (fn, fs, ff) = O.voc_transform(v, feat, levelsup)
+    fixb.update({"cfg_" + tag: np.array([weighting, scoring, levelsup], np.int32), "wid_" + tag: wid, "nid_" + tag: nid,
+                 "bi_" + tag: bi, "bv_" + tag: bv, "fn_" + tag: fn, "fs_" + tag: fs, "ff_" + tag: ff})
+np.savez_compressed(os.path.join(out, "bow_k8_L3.npz"), **fixb)
+if sys.argv[1:] == ["bow"]:
+    print("vocabulary fixture written to", out)
+    sys.exit(0)
 
 # 1. extraction on two small frames (pyramid checksums, keypoints, descriptors)
 seq = synth.sequence(320, 240, 2, seed=3)
