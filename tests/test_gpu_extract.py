@@ -90,6 +90,82 @@ def test_end_to_end_configs(oracle, w, h, nfeat, seed):
     assert int((desc != odesc).any(axis=1).sum()) <= 0.001 * len(desc)
 
 
+def _compare(ex, oe, img):
+    kps, desc = ex(img)
+    okps, odesc = oe.extract(img)
+    assert len(kps) == len(okps)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(kps[f], okps[f]), f
+    if len(kps):
+        dang = np.abs(kps["angle"] - okps["angle"])
+        assert np.minimum(dang, 360 - dang).max() <= np.degrees(1e-4)
+    assert int((desc != odesc).any(axis=1).sum()) <= 0.001 * len(desc)
+    return kps, desc
+
+
+@pytest.mark.parametrize("nfeat,scale,nlevels,ini,mn,gauss", [
+    (1000, 1.2, 8, 20, 7, 1),    # the 18,34,48,56,... Gaussian taps of newer OpenCV
+    (800, 1.5, 5, 20, 7, 0), (1500, 1.1, 12, 20, 7, 0), (600, 2.0, 3, 20, 7, 0), (500, 1.2, 1, 20, 7, 0),
+    (1000, 1.2, 8, 40, 5, 0), (1000, 1.2, 8, 12, 12, 0), (40, 1.2, 8, 20, 7, 0), (3000, 1.2, 8, 9, 3, 0)])
+def test_parameter_variants(oracle, nfeat, scale, nlevels, ini, mn, gauss):
+    """Constructor arguments other than the shipped YAML settings: scale factor, level count, FAST thresholds,
+    feature budget, Gaussian variant."""
+    from orb_slam2_amd.api import ORBextractor
+    img = synth.sequence(640, 480, 1, seed=int(nfeat + nlevels))[0]
+    ex = ORBextractor(nfeat, scale, nlevels, ini, mn, max_width=640, max_height=480, gauss_variant=gauss)
+    oe = oracle.Extractor(nfeat, scale, nlevels, ini, mn, gauss_variant=gauss)
+    t = oracle.tables(oe.p)
+    assert np.array_equal(ex.GetScaleFactors(), t["scale"]) and np.array_equal(ex.mnFeaturesPerLevel, t["quota"])
+    kps, _ = _compare(ex, oe, img)
+    assert len(kps) > min(nfeat, 300) * 0.5
+    for l in range(nlevels):
+        assert np.array_equal(ex.pyramid_level(l), oe.level(l)), "level %d" % l
+        rb = oe.level(l, blurred=True)
+        if rb is not None:
+            assert np.array_equal(ex.pyramid_level(l, blurred=True), rb), "blurred level %d" % l
+
+
+def test_handmade_corner_patterns(oracle):
+    """Flat background with hand-placed structures: isolated bright and dark squares of known contrast (also on
+    the seams between FAST cells and at the 16 px border of the search area), two-pixel-wide bars whose adjacent
+    corners tie and suppress each other, weak structures only the fallback threshold detects."""
+    img = np.full((480, 640), 100, np.uint8)
+    rng = np.random.default_rng(5)
+
+    def square(x, y, s, v):
+        img[y:y + s, x:x + s] = v
+    # cells of level 0 are 31 x 32 px starting at (16, 16): put structures on their seams and corners
+    for j in range(0, 19):
+        for i in range(0, 13):
+            x, y = 16 + 31 * j, 16 + 32 * i
+            kind = (i * 19 + j) % 6
+            if kind == 0:
+                square(x - 2, y - 2, 5, 100 + 60)      # strong bright square across a cell corner
+            elif kind == 1:
+                square(x + 10, y - 1, 4, 100 - 55)     # dark square across a horizontal seam
+            elif kind == 2:
+                square(x - 1, y + 12, 2, 100 + 90)     # 2 x 2 block: four tied corners
+            elif kind == 3:
+                square(x + 8, y + 9, 6, 100 + 11)      # weak: below iniTh, above minTh
+            elif kind == 4:
+                img[y + 5:y + 25, x + 14:x + 16] = 30  # two-pixel-wide bar: tied ends
+            else:
+                square(x + 5, y + 5, 3, int(rng.integers(0, 256)))
+    square(14, 14, 6, 220); square(620, 460, 6, 10); square(0, 0, 12, 255); square(628, 468, 12, 0)  # at the borders
+    ex = _mk(640, 480, 1000)
+    oe = oracle.Extractor(1000)
+    kps, _ = _compare(ex, oe, img)
+    assert len(kps) > 200
+    for l in range(8):
+        ref = oe.level(l)
+        cx, cy, cr = oracle.level_candidates(ref)
+        gx, gy, gr = ex.debug_level_candidates(l)
+        assert np.array_equal(gx, cx.astype(np.int32)) and np.array_equal(gy, cy.astype(np.int32))
+        assert np.array_equal(gr, cr.astype(np.int32))
+    # the weak squares are found only through the fallback: their cells yield responses below iniTh
+    assert (kps["response"] < 20).any() and (kps["response"] >= 20).any()
+
+
 def test_batch_equals_single(oracle):
     seq = synth.sequence(640, 480, 4, seed=21)
     ex = _mk(640, 480, 1000, max_batch=4)
