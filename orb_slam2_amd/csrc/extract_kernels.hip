@@ -181,11 +181,17 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
 // ---------------------------------------------------------------------------
 // FAST-9/16 per 30 px cell with ini/min threshold fallback and in-cell
 // non-maximum suppression (src/ORBextractor.cc:1043-1107; cv::FAST semantics).
-// One workgroup per (cell, frame).  Output: per-cell ordered list of packed
-// candidates in a fixed-capacity slot + the count.
+// One workgroup per (run of kFastQuad cells, frame).  Output: per-cell ordered
+// list of packed candidates in a fixed-capacity slot + the count.
 // ---------------------------------------------------------------------------
-constexpr int kFastThreads = 128;  // threads of a FAST workgroup (one cell)
-constexpr int kTP = 72;  // LDS tile pitch in bytes (18 dwords: a 66 px row + up to 3 bytes of alignment slack)
+#ifdef ORBGPU_STAMPS
+// Debug build only (make CXXFLAGS+=-DORBGPU_STAMPS, tools/fast_stamps.py): cycle counter deltas of the kernel's
+// phases per workgroup.
+constexpr int kStampWgs = 1 << 19;
+__device__ unsigned g_fast_stamps[8 * kStampWgs];
+#endif
+constexpr int kFastThreads = 128;  // threads of a FAST workgroup
+constexpr int kTP = 72;  // LDS tile pitch in bytes (18 dwords: one lead byte + a 66 px row, rounded up)
 
 // Strength A of the best 9-long arc: max over the 16 arcs of the minimum
 // signed contrast, both polarities.  A pixel is a FAST corner at threshold t
@@ -220,78 +226,196 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
 // i / d for 0 <= i < 4096, 1 <= d <= 66, with m = ceil(2^20 / d)
 __device__ __forceinline__ int div_small(int i, int m) { return (int)(__umul24((unsigned)i, (unsigned)m) >> 20); }
 
+constexpr int kFastQuad = 4;  // consecutive cells per workgroup
+
+// One FAST cell: geometry of :1043-1072 and where its pixels lie.
+struct FastCell {
+    int state;  // 0: past the last cell, 1: skipped by the rules of :1053 / :1068 (count 0), 2: to be searched
+    int l, ci, ci_i, ci_j, cw, ch, ndw, pitch;
+    const uint8_t *src;  // the byte left of the cell image's first pixel
+};
+
+__device__ __forceinline__ FastCell fast_cell_info(const uint8_t *__restrict__ pyr, const Geom &G, const uint32_t *__restrict__ cell_tab, int f,
+                                                   int cell)
+{
+    FastCell c;
+    c.state = 0;
+    if (cell >= G.total_cells) return c;
+    // cell_tab: level | cell row << 8 | cell column << 20
+    const uint32_t ct = cell_tab[cell];
+    c.l = ct & 0xFF; c.ci_i = (ct >> 8) & 0xFFF; c.ci_j = ct >> 20;
+    const LevelGeom &g = G.lv[c.l];
+    c.ci = cell - g.cell_off;
+    const int maxBX = g.w - kMinBorder, maxBY = g.h - kMinBorder;
+    const int iniY = kMinBorder + c.ci_i * g.hCell, iniX = kMinBorder + c.ci_j * g.wCell;
+    c.state = 1;
+    // skip rules of :1053 and :1068 (the column rule uses 6, the row rule 3)
+    if (iniY >= maxBY - 3 || iniX >= maxBX - 6) return c;
+    c.cw = min(iniX + g.wCell + 6, maxBX) - iniX;
+    c.ch = min(iniY + g.hCell + 6, maxBY) - iniY;
+    if (c.cw <= 6 || c.ch <= 6) return c;
+    // The cell image goes one byte into the tile rows (tile byte 1 + x of row y = cell image (x, y)): the interior,
+    // cell image column 3, then starts on a dword boundary.  The copy reads dwords at byte addresses.
+    c.ndw = (c.cw + 4) >> 2;
+    c.pitch = g.pitch;
+    c.src = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)iniY * g.pitch + (iniX - 1);
+    c.state = 2;
+    return c;
+}
+
+typedef __attribute__((address_space(3))) void fast_lvoid;
+
+// Copy a cell image into a tile buffer (rows of kTP bytes) with direct global -> LDS loads: no registers, and the
+// copy proceeds while the wave computes.  One wave instruction writes 64 consecutive dwords of the buffer, so lane
+// L of piece p owns dword 64 p + L = (row, column) of the tile; rows and columns past the cell re-read its last
+// row / dword (the buffer is padded to whole pieces).  The loads are issued from an asm statement: issued through
+// the builtin, the compiler orders every later LDS write and atomic of the wave behind them (it cannot see that
+// they go to the other buffer), which would stall the wave until the copy has landed.  The caller therefore
+// waits itself (fast_stage_wait) before the barrier that precedes the first read of the buffer.
+__device__ __forceinline__ void fast_stage_cell(const FastCell &c, uint8_t *buf, int wave, int lane)
+{
+    const int npieces = (c.ch * (kTP / 4) + 63) >> 6;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(fast_lvoid *)buf;
+    for (int p = wave; p < npieces; p += kFastThreads / 64) {
+        const int d = (p << 6) + lane;
+        const int row = (d * 3641) >> 16;  // d / 18 for d < 2^15
+        const int col = d - row * (kTP / 4);
+        const uint8_t *gp = c.src + (uint32_t)min(row, c.ch - 1) * (uint32_t)c.pitch + 4u * (uint32_t)min(col, c.ndw - 1);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + ((uint32_t)p << 8));
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gp), "s"(dst)
+                     : "memory");
+    }
+}
+__device__ __forceinline__ void fast_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G, const uint32_t *__restrict__ cell_tab,
                                                     uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts,
-                                                    int lds_score_off, int lds_maxima_off, int lds_queue_off)
+                                                    int lds_tile_bytes, int lds_score_off, int lds_maxima_off, int lds_queue_off)
 {
     // dynamic LDS, sized by the launcher for the largest cell of the geometry:
-    // tile | score (interior + 1 px zero border) | maxima | queue
+    // tile x 2 | score (interior + 1 px zero border) | maxima | queue
     extern __shared__ __align__(16) uint8_t fast_lds[];
     uint8_t *tile = fast_lds;
     uint8_t *score = tile + lds_score_off;
     uint32_t *maxima = reinterpret_cast<uint32_t *>(tile + lds_maxima_off);  // strict 3x3 maxima are never adjacent
     uint16_t *queue = reinterpret_cast<uint16_t *>(tile + lds_queue_off);
     __shared__ int qn, nmax, nini;
+#ifdef ORBGPU_STAMPS
+    unsigned long long stamp_prev = __builtin_readcyclecounter();
+    const unsigned stamp_wg = blockIdx.y * gridDim.x + blockIdx.x;
+#define ORB_STAMP(k_) do { if (threadIdx.x == 0 && stamp_wg < (unsigned)kStampWgs) { const unsigned long long now_ = __builtin_readcyclecounter(); g_fast_stamps[stamp_wg * 8 + k_] += (unsigned)(now_ - stamp_prev); stamp_prev = now_; } } while (0)
+#else
+#define ORB_STAMP(k_) do { } while (0)
+#endif
 
-    // Workgroups are dealt to the 8 XCDs round-robin.  Within every run of 32 cells, workgroups
-    // b, b+8, b+16, b+24 (one XCD) take four consecutive cells: horizontal neighbours read the
-    // same 128-byte lines of the pyramid, so they should meet in one L2.
+    // A workgroup searches kFastQuad consecutive cells (horizontal neighbours: they share 128-byte lines of the
+    // pyramid).  While one cell is searched in one tile buffer the next is copied into the other, so the
+    // global-memory latency of the staging is paid once per workgroup, not once per cell.
     const int f = blockIdx.y, tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const int cell = (b & ~31) + ((b & 7) << 2) + ((b >> 3) & 3);
-    if (cell >= G.total_cells) return;
-    // cell_tab: level | cell row << 8 | cell column << 20
-    const uint32_t ct = cell_tab[cell];
-    const int l = ct & 0xFF, ci_i = (ct >> 8) & 0xFFF, ci_j = ct >> 20;
-    const LevelGeom &g = G.lv[l];
-    const int ci = cell - g.cell_off;
-    const int maxBX = g.w - kMinBorder, maxBY = g.h - kMinBorder;
-    const int iniY = kMinBorder + ci_i * g.hCell, iniX = kMinBorder + ci_j * g.wCell;
-    int32_t *cnt_out = cell_counts + (int64_t)f * G.total_cells + cell;
-    // skip rules of :1053 and :1068 (the column rule uses 6, the row rule 3)
-    if (iniY >= maxBY - 3 || iniX >= maxBX - 6) {
-        if (tid == 0) *cnt_out = 0;
-        return;
-    }
-    const int cw = min(iniX + g.wCell + 6, maxBX) - iniX, ch = min(iniY + g.hCell + 6, maxBY) - iniY;
-    const int wi = cw - 6, hi = ch - 6;
-    if (wi <= 0 || hi <= 0) {
-        if (tid == 0) *cnt_out = 0;
-        return;
-    }
-    // Stage the cell with aligned 32-bit loads: rows start 32-byte aligned in the
-    // plane, so the cell's first column sits ox = iniX & 3 bytes into its first dword.
-    const int ox = iniX & 3;
-    const int ndw = (ox + cw + 3) >> 2;
-    const uint8_t *src = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)iniY * g.pitch + (iniX - ox);
-    {
-        const int c = tid & 31, r0 = tid >> 5;
-        if (c < ndw)
-            for (int r = r0; r < ch; r += kFastThreads / 32)
-                reinterpret_cast<uint32_t *>(tile)[r * (kTP / 4) + c] = *reinterpret_cast<const uint32_t *>(src + (int64_t)r * g.pitch + 4 * c);
-    }
+    const int cell0 = blockIdx.x * kFastQuad;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    FastCell nx = fast_cell_info(pyr, G, cell_tab, f, cell0);
+    if (nx.state == 2) fast_stage_cell(nx, tile, wave, lane);
+#pragma unroll 1
+    for (int k = 0; k < kFastQuad; k++) {
+        const FastCell cu = nx;
+        if (cu.state == 0) break;
+        const int cell = cell0 + k;
+        int32_t *cnt_out = cell_counts + (int64_t)f * G.total_cells + cell;
+        uint8_t *cur = tile + (k & 1) * lds_tile_bytes, *nxt = tile + ((k + 1) & 1) * lds_tile_bytes;
+        if (k + 1 < kFastQuad) nx = fast_cell_info(pyr, G, cell_tab, f, cell + 1);
+        else nx.state = 0;
+        if (cu.state == 1) {
+            if (tid == 0) *cnt_out = 0;
+            // the other buffer was last read before the barrier that ended the previous cell
+            if (nx.state == 2) fast_stage_cell(nx, nxt, wave, lane);
+            continue;
+        }
+        const LevelGeom &g = G.lv[cu.l];
+        const int ci = cu.ci, ci_i = cu.ci_i, ci_j = cu.ci_j;
+        const int wi = cu.cw - 6, hi = cu.ch - 6;
     for (int i = tid; i < ((hi + 2) * (kTP / 4) + 3) / 4; i += kFastThreads) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) { qn = 0; nmax = 0; nini = 0; }
+    fast_stage_wait();  // the first cell's copy (later cells were waited for below)
     __syncthreads();
+    ORB_STAMP(1);
+    if (nx.state == 2) fast_stage_cell(nx, nxt, wave, lane);  // lands during the rejection stage
 
-    // stage 1: cheap rejection at the lower threshold; survivors are compacted
-    // into a queue so the expensive arc evaluation runs on dense waves.
+    // stage 1: cheap rejection at the lower threshold, four horizontally adjacent pixels per lane: any 9-long
+    // arc contains one pixel of each opposite pair (k, k+8), so a corner needs the brighter of every even pair
+    // below v - t or the darker of every even pair above v + t.  The ring bytes come out of 11 aligned dword
+    // reads through byte permutes as 16-bit pairs (pixels 0|2 and 1|3 of the group), the test is packed 16-bit
+    // min / max / subtract and the verdicts are the sign bits.  Survivors go to a dense pixel queue for the
+    // arc evaluation.
     const int t = G.minTh;
-    const int npix = wi * hi;
     const int mdiv = ((1 << 20) + wi - 1) / wi;
-    const uint8_t *t0 = tile + ox;  // pixel (x, y) of the cell image is t0[y * kTP + x]
-    for (int i = tid; i < npix; i += kFastThreads) {
-        const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
-        const uint8_t *c = t0 + (y + 3) * kTP + (x + 3);
-        const int v = c[0], lo = v - t, hi_ = v + t;
-        // any 9-long arc contains one pixel of each opposite pair (k, k+8)
-        const int p0 = c[3 * kTP], p8 = c[-3 * kTP], p4 = c[3], p12 = c[-3];
-        const int p2 = c[2 * kTP + 2], p10 = c[-2 * kTP - 2], p6 = c[-2 * kTP + 2], p14 = c[2 * kTP - 2];
-        const int dmax = max(max(min(p0, p8), min(p4, p12)), max(min(p2, p10), min(p6, p14)));
-        const int bmin = min(min(max(p0, p8), max(p4, p12)), min(max(p2, p10), max(p6, p14)));
-        if (dmax < lo || bmin > hi_) queue[atomicAdd(&qn, 1)] = (uint16_t)i;
+    const uint8_t *t0 = cur + 1;  // pixel (x, y) of the cell image is t0[y * kTP + x]
+    const uint32_t *tile32 = reinterpret_cast<const uint32_t *>(cur);
+    const int ngx = (wi + 3) >> 2, ngroups = ngx * hi;  // groups of four interior pixels = dwords 1 .. ngx of a tile row
+    const int mdivg = ((1 << 20) + ngx - 1) / ngx;
+    {
+        const short2v tt = __builtin_bit_cast(short2v, (uint32_t)t * 0x10001u);
+        constexpr int RP = kTP / 4;
+        constexpr uint32_t kSel02 = 0x0c020c00u, kSel13 = 0x0c030c01u, kSel24 = 0x0c040c02u, kSel35 = 0x0c050c03u, kSel46 = 0x0c060c04u;
+        for (int i = tid; i < ngroups; i += kFastThreads) {
+            const int y = div_small(i, mdivg), gx = i - (int)__umul24(y, ngx);
+            // rows y .. y+6 of the tile, three dwords each; the group's pixels are the bytes of the middle dword of row y+3
+            const uint32_t *r = tile32 + y * RP + gx;
+            const uint32_t P8 = r[1], Am = r[RP], A0 = r[RP + 1], A1 = r[RP + 2];
+            const uint32_t Cm = r[3 * RP], C0 = r[3 * RP + 1], C1 = r[3 * RP + 2];
+            const uint32_t Bm = r[5 * RP], B0 = r[5 * RP + 1], B1 = r[5 * RP + 2], P0 = r[6 * RP + 1];
+            uint32_t verdict[2];
+#pragma unroll
+            for (int odd = 0; odd < 2; odd++) {
+                // byte offsets of the ring from the group's first byte: pixels j = odd, odd + 2
+                const uint32_t selc = odd ? kSel13 : kSel02;   // column 0
+                const uint32_t selp3 = odd ? kSel46 : kSel35;  // column +3 from (C1, C0)
+                const uint32_t selm3 = odd ? kSel24 : kSel13;  // column -3 from (C0, Cm)
+                const uint32_t selp2 = odd ? kSel35 : kSel24;  // column +2 from (x1, x0); column -2 from (x0, xm)
+#define ORB_P(hi_, lo_, sel_) __builtin_bit_cast(short2v, __builtin_amdgcn_perm(hi_, lo_, sel_))
+                const short2v v = ORB_P(0u, C0, selc), p0 = ORB_P(0u, P0, selc), p8 = ORB_P(0u, P8, selc);
+                const short2v p4 = ORB_P(C1, C0, selp3), p12 = ORB_P(C0, Cm, selm3);
+                const short2v p2 = ORB_P(B1, B0, selp2), p14 = ORB_P(B0, Bm, selp2);
+                const short2v p6 = ORB_P(A1, A0, selp2), p10 = ORB_P(A0, Am, selp2);
+#undef ORB_P
+#define ORB_MIN(a_, b_) __builtin_elementwise_min(a_, b_)
+#define ORB_MAX(a_, b_) __builtin_elementwise_max(a_, b_)
+                const short2v dmax = ORB_MAX(ORB_MAX(ORB_MIN(p0, p8), ORB_MIN(p4, p12)), ORB_MAX(ORB_MIN(p2, p10), ORB_MIN(p6, p14)));
+                const short2v bmin = ORB_MIN(ORB_MIN(ORB_MAX(p0, p8), ORB_MAX(p4, p12)), ORB_MIN(ORB_MAX(p2, p10), ORB_MAX(p6, p14)));
+#undef ORB_MIN
+#undef ORB_MAX
+                // dmax < v - t  or  bmin > v + t, as the signs of two differences (all values within +-510)
+                verdict[odd] = __builtin_bit_cast(uint32_t, dmax - (v - tt)) | __builtin_bit_cast(uint32_t, (v + tt) - bmin);
+            }
+            const uint32_t S = (verdict[0] & 0x80008000u) | ((verdict[1] & 0x80008000u) >> 1);
+            // bits 15 / 14 / 31 / 30 of S = pixels 0 / 1 / 2 / 3; pixels beyond the interior's last column were tested
+            // on whatever lies there and are dropped.  Survivors are appended to the pixel queue with one LDS atomic
+            // per wave: positions from ballots (the queue's order does not matter, emission ranks by pixel index).
+            const int x0 = gx << 2, left = wi - x0;
+            const int pix0 = (int)__umul24(y, wi) + x0;
+            const bool s0 = (S & 0x8000u) != 0, s1 = (S & 0x4000u) != 0 && left > 1, s2 = (S & 0x80000000u) != 0 && left > 2,
+                       s3 = (S & 0x40000000u) != 0 && left > 3;
+            const uint64_t m0 = __ballot(s0), m1 = __ballot(s1), m2 = __ballot(s2), m3 = __ballot(s3);
+            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+            if (n0 + n1 + n2 + n3) {  // wave-uniform
+                int base = 0;
+                const uint64_t act = __ballot(true);
+                if (lane_id() == __ffsll((long long)act) - 1) base = atomicAdd(&qn, n0 + n1 + n2 + n3);
+                base = __builtin_amdgcn_readfirstlane(base);
+#define ORB_RANK(m_) (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m_) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m_), 0u))
+                if (s0) queue[base + ORB_RANK(m0)] = (uint16_t)pix0;
+                if (s1) queue[base + n0 + ORB_RANK(m1)] = (uint16_t)(pix0 + 1);
+                if (s2) queue[base + n0 + n1 + ORB_RANK(m2)] = (uint16_t)(pix0 + 2);
+                if (s3) queue[base + n0 + n1 + n2 + ORB_RANK(m3)] = (uint16_t)(pix0 + 3);
+#undef ORB_RANK
+            }
+        }
     }
     __syncthreads();
+    ORB_STAMP(2);
     const int nq = qn;
     for (int q = tid; q < nq; q += kFastThreads) {
         const int i = queue[q];
@@ -300,6 +424,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
         if (A > t) score[(y + 1) * kTP + (x + 1)] = (uint8_t)(A - 1);
     }
     __syncthreads();
+    ORB_STAMP(4);
     // stage 2: strict 3x3 maximum inside the cell, evaluated for the corners only;
     // a maximum is listed as pixel index | initial-threshold flag << 12 | score << 16
     for (int q = tid; q < nq; q += kFastThreads) {
@@ -317,6 +442,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
         }
     }
     __syncthreads();
+    ORB_STAMP(5);
 
     // stage 3: threshold choice (:1071-1082) and row-major emission: the position of
     // a maximum in the output is its rank by pixel index among the chosen ones
@@ -337,6 +463,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
         if (pos < g.cell_cap) slot[pos] = pack_cand(x + 3 + ci_j * g.wCell, y + 3 + ci_i * g.hCell, (int)(e >> 16));
     }
     if (tid == 0) *cnt_out = min(count, g.cell_cap);
+    fast_stage_wait();  // the next cell's copy: every wave waits for its own pieces, the barrier joins them
+    __syncthreads();    // the next cell also reuses the score plane and the counters
+    ORB_STAMP(6);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1188,6 +1318,20 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     return ORBGPU_OK;
 }
 
+#ifdef ORBGPU_STAMPS
+extern "C" int orbgpu_debug_fast_stamps(unsigned *out, int nwg, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (nwg > kStampWgs) nwg = kStampWgs;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fast_stamps), (size_t)nwg * 32) != hipSuccess) return -1;
+    if (reset) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fast_stamps)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * 8 * kStampWgs) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
                 int32_t *cell_counts)
 {
@@ -1197,11 +1341,12 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
         wmax = G.lv[l].wCell > wmax ? G.lv[l].wCell : wmax;
         hmax = G.lv[l].hCell > hmax ? G.lv[l].hCell : hmax;
     }
-    const int score_off = (hmax + 6) * kTP, maxima_off = score_off + (((hmax + 2) * kTP + 15) & ~15);
+    const int tile_bytes = ((hmax + 6) * kTP + 255) & ~255;  // whole 64-dword pieces of the direct global -> LDS copy
+    const int score_off = 2 * tile_bytes, maxima_off = score_off + (((hmax + 2) * kTP + 15) & ~15);
     const int queue_off = maxima_off + ((((wmax + 1) / 2) * ((hmax + 1) / 2) * 4 + 15) & ~15);
     const size_t lds = (size_t)queue_off + (size_t)wmax * hmax * 2;
-    hipLaunchKernelGGL(k_fast_cells, dim3((G.total_cells + 31) & ~31, nimg), dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots, cell_counts,
-                       score_off, maxima_off, queue_off);
+    hipLaunchKernelGGL(k_fast_cells, dim3((G.total_cells + kFastQuad - 1) / kFastQuad, nimg), dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots,
+                       cell_counts, tile_bytes, score_off, maxima_off, queue_off);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
