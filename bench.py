@@ -232,6 +232,22 @@ def main():
                 traffic = (kk["FETCH_SIZE_KB_per_launch"] * kk.get("fetch_corr", 1.0) + kk["WRITE_SIZE_KB_per_launch"]) * 1024
         except Exception:
             traffic = None
+        # vector-issue view of the same kernel: SQ_INSTS_VALU per launch from the committed PMC pass (same launch size
+        # only) over the isolated launch time, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 integer instruction
+        valu = None
+        try:
+            if Bs == 512:
+                kname = {"pyramid": "k_pyr_resize", "fast_cells": "k_fast_cells", "octree": "k_octree_batch", "blur": "k_blur",
+                         "describe": "k_describe"}[dom_name]
+                for line in open(os.path.join(ROOT, "profiles", "r01_sq_counters.txt")):
+                    f = line.split()
+                    if f and f[0] == kname:
+                        insts = float(f[2])
+                        peak = 1024 * 2.4e9 / 4
+                        valu = {"wave_instructions_per_launch": insts, "achieved_Ginstr_per_s": insts / (float(iso_ms[dom]) * 1e-3) / 1e9,
+                                "peak_Ginstr_per_s": peak / 1e9, "frac": insts / (float(iso_ms[dom]) * 1e-3) / peak}
+        except Exception:
+            valu = None
         frame_alg = W * H + (P - W * H) + P + 2 * P + int(kp_mean * 60)
         out = {
             "metric": "frames/sec ORB extract+match at 640x480/1000 kp",
@@ -254,6 +270,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": float(stage_ms[dom]),
                          "launch_ms_isolated": float(iso_ms[dom]), "achieved_isolated": dom_bytes / (float(iso_ms[dom]) * 1e-3) / 1e9,
+                         "valu_issue": valu,
                          "note": "integer byte kernels: the binding limit is vector-ALU issue (1 wave-instr / 4 cycles / SIMD), "
                                  "see profiles/r01_sq_counters.txt; traffic = committed rocprofv3 PMC passes of this workload"},
             "stages_ms_per_step": dict({n: float(v) for n, v in zip(names, stage_ms)}, match=match_ms),

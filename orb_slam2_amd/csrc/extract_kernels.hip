@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
 // ---------------------------------------------------------------------------
 // FAST-9/16 per 30 px cell with ini/min threshold fallback and in-cell
 // non-maximum suppression (src/ORBextractor.cc:1043-1107; cv::FAST semantics).
-// One workgroup per (run of kFastQuad cells, frame).  Output: per-cell ordered
+// One workgroup per (run of cells, frame).  Output: per-cell ordered
 // list of packed candidates in a fixed-capacity slot + the count.
 // ---------------------------------------------------------------------------
 #ifdef ORBGPU_STAMPS
@@ -226,7 +226,7 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
 // i / d for 0 <= i < 4096, 1 <= d <= 66, with m = ceil(2^20 / d)
 __device__ __forceinline__ int div_small(int i, int m) { return (int)(__umul24((unsigned)i, (unsigned)m) >> 20); }
 
-constexpr int kFastQuad = 4;  // consecutive cells per workgroup
+constexpr int kFastQuad = 4;  // consecutive cells per workgroup in batch launches (one cell per workgroup for a few frames)
 
 // One FAST cell: geometry of :1043-1072 and where its pixels lie.
 struct FastCell {
@@ -293,7 +293,8 @@ __device__ __forceinline__ void fast_stage_wait() { asm volatile("s_waitcnt vmcn
 
 __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G, const uint32_t *__restrict__ cell_tab,
                                                     uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts,
-                                                    int lds_tile_bytes, int lds_score_off, int lds_maxima_off, int lds_queue_off)
+                                                    int cells_per_wg, int lds_tile_bytes, int lds_score_off, int lds_maxima_off,
+                                                    int lds_queue_off)
 {
     // dynamic LDS, sized by the launcher for the largest cell of the geometry:
     // tile x 2 | score (interior + 1 px zero border) | maxima | queue
@@ -311,22 +312,22 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
 #define ORB_STAMP(k_) do { } while (0)
 #endif
 
-    // A workgroup searches kFastQuad consecutive cells (horizontal neighbours: they share 128-byte lines of the
+    // A workgroup searches cells_per_wg consecutive cells (horizontal neighbours: they share 128-byte lines of the
     // pyramid).  While one cell is searched in one tile buffer the next is copied into the other, so the
     // global-memory latency of the staging is paid once per workgroup, not once per cell.
     const int f = blockIdx.y, tid = threadIdx.x;
-    const int cell0 = blockIdx.x * kFastQuad;
+    const int cell0 = blockIdx.x * cells_per_wg;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     FastCell nx = fast_cell_info(pyr, G, cell_tab, f, cell0);
     if (nx.state == 2) fast_stage_cell(nx, tile, wave, lane);
 #pragma unroll 1
-    for (int k = 0; k < kFastQuad; k++) {
+    for (int k = 0; k < cells_per_wg; k++) {
         const FastCell cu = nx;
         if (cu.state == 0) break;
         const int cell = cell0 + k;
         int32_t *cnt_out = cell_counts + (int64_t)f * G.total_cells + cell;
         uint8_t *cur = tile + (k & 1) * lds_tile_bytes, *nxt = tile + ((k + 1) & 1) * lds_tile_bytes;
-        if (k + 1 < kFastQuad) nx = fast_cell_info(pyr, G, cell_tab, f, cell + 1);
+        if (k + 1 < cells_per_wg) nx = fast_cell_info(pyr, G, cell_tab, f, cell + 1);
         else nx.state = 0;
         if (cu.state == 1) {
             if (tid == 0) *cnt_out = 0;
@@ -1345,8 +1346,11 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
     const int score_off = 2 * tile_bytes, maxima_off = score_off + (((hmax + 2) * kTP + 15) & ~15);
     const int queue_off = maxima_off + ((((wmax + 1) / 2) * ((hmax + 1) / 2) * 4 + 15) & ~15);
     const size_t lds = (size_t)queue_off + (size_t)wmax * hmax * 2;
-    hipLaunchKernelGGL(k_fast_cells, dim3((G.total_cells + kFastQuad - 1) / kFastQuad, nimg), dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots,
-                       cell_counts, tile_bytes, score_off, maxima_off, queue_off);
+    // runs of cells per workgroup hide the staging latency when there are many more workgroups than the chip
+    // holds at once; with a few frames the cells are better spread over all CUs
+    const int per_wg = (int64_t)G.total_cells * nimg >= 16384 ? kFastQuad : 1;
+    hipLaunchKernelGGL(k_fast_cells, dim3((G.total_cells + per_wg - 1) / per_wg, nimg), dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots,
+                       cell_counts, per_wg, tile_bytes, score_off, maxima_off, queue_off);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
