@@ -28,7 +28,7 @@ __device__ __forceinline__ void store_row_span(uint8_t *row, int x0, int n, cons
 
 // A span of a level plus its reflect-101 image in the halo rows above/below
 // (copyMakeBorder BORDER_REFLECT_101, src/ORBextractor.cc:1567-1586); the halo
-// columns are filled by k_halo_sides.  Needs h >= 2*kEdge+2.
+// columns are filled by k_halo4 / k_halo_sides.  Needs h >= 2*kEdge+2.
 template <int NW>
 __device__ __forceinline__ void store_span_with_halo(uint8_t *in, int pitch, int w, int h, int x0, int y, int n,
                                                      const uint32_t (&v)[NW])
@@ -63,6 +63,34 @@ __global__ __launch_bounds__(256) void k_halo_sides(uint8_t *__restrict__ pyr, G
 #pragma unroll
     for (int r = 0; r < 4; r++)
         if (y0 + r < g.h + kEdge) row[(int64_t)r * g.pitch + x] = v[r];
+}
+
+// The four halo columns next to the interior on each side, every level and every row (halo rows included): all
+// that the extraction itself reads beyond the interior (the blur reaches 3 px).  A thread mirrors one side of one
+// row: columns -4..-1 = columns 4..1, columns w..w+3 = columns w-2..w-5.  k_halo_sides completes the 19 columns
+// when a caller asks for a level with its border.
+__global__ __launch_bounds__(64) void k_halo4(uint8_t *__restrict__ pyr, Geom G)
+{
+    const int f = blockIdx.y;
+    int b = blockIdx.x, l = 0;  // a workgroup = 32 rows x 2 sides of one level
+    while (true) {
+        const int n = (G.lv[l].h + 2 * kEdge + 31) >> 5;
+        if (b < n) break;
+        b -= n;
+        if (++l >= G.nlevels) return;
+    }
+    const LevelGeom &g = G.lv[l];
+    const int y = b * 32 + (threadIdx.x >> 1) - kEdge;
+    if (y >= g.h + kEdge) return;
+    uint8_t *row = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch;
+    if (threadIdx.x & 1) {
+        // byte addresses: w is arbitrary
+        const uint32_t s = *reinterpret_cast<const uint32_t *>(row + g.w - 5);
+        *reinterpret_cast<uint32_t *>(row + g.w) = __builtin_amdgcn_perm(0u, s, 0x00010203u);
+    } else {
+        const uint2 s = *reinterpret_cast<const uint2 *>(row);  // rows are 32-byte aligned
+        *reinterpret_cast<uint32_t *>(row - 4) = __builtin_amdgcn_perm(s.y, s.x, 0x01020304u);
+    }
 }
 
 // Level 0 = the input image; 16 pixels per thread, 128-bit accesses when the
@@ -957,7 +985,8 @@ __global__ __launch_bounds__(256, 8) void k_octree_batch(OCTREE_ARGS)
 // computes four horizontally adjacent pixels (32-bit global accesses, 64-bit
 // LDS accesses for the 16-bit row sums).
 // ---------------------------------------------------------------------------
-constexpr int kBW = 128, kBH = 32;
+constexpr int kBW = 64, kBH = 32;        // output tile of one blur workgroup
+constexpr int kBlurThreads = (kBW / 4) * (kBH / 8);  // a thread of the vertical pass: 4 columns x 8 rows; = one wave
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t w, uint32_t acc)
@@ -975,7 +1004,11 @@ __device__ __forceinline__ void blur_row4(uint32_t a, uint32_t b, uint32_t d, ui
     o[3] = __builtin_amdgcn_udot4(d, khi, __builtin_amdgcn_udot4(b, klo, 0u, false), false);
 }
 
-__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G)
+__device__ __forceinline__ uint32_t u4_at(const uint4 &v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
+// One wave per 64 x 32 tile: narrow tiles waste few lanes on the level widths, and the 19 x 16 horizontal tasks
+// fill five passes of the wave almost completely.
+__global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G)
 {
     // horizontal sums (16 bit) of source rows 2i and 2i+1 share a dword: hpair[i][x] = h[2i][x] | h[2i+1][x] << 16
     __shared__ __align__(16) uint32_t hpair[(kBH + 6) / 2 * kBW];
@@ -1000,8 +1033,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     // a thread takes two source rows x four columns (three aligned dwords per row: neighbours'
     // loads overlap in L1) and writes four packed dwords
     const int xlim = (g.w + 15) & ~3, ylim = g.h + 2;
-    for (int i = tid; i < (kBH + 6) / 2 * (kBW / 4); i += 256) {
-        const int rp = i >> 5, c = i & 31;
+    constexpr int CG = kBW / 4;  // column groups of a tile row
+    for (int i = tid; i < (kBH + 6) / 2 * CG; i += kBlurThreads) {
+        const int rp = i / CG, c = i % CG;
         const int y0 = min(ty0 + 2 * rp - 3, ylim), y1 = min(ty0 + 2 * rp - 2, ylim);
         const int xa = min(tx0 - 4 + 4 * c, xlim), xb = min(tx0 + 4 * c, xlim), xd = min(tx0 + 4 + 4 * c, xlim);
         const uint8_t *r0 = in + (int64_t)y0 * g.pitch, *r1 = in + (int64_t)y1 * g.pitch;
@@ -1013,26 +1047,23 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         *reinterpret_cast<uint4 *>(hpair + rp * kBW + 4 * c) = make_uint4(e[0] | (o[0] << 16), e[1] | (o[1] << 16), e[2] | (o[2] << 16), e[3] | (o[3] << 16));
     }
     __syncthreads();
-    // vertical pass: thread = 4 columns x 4 rows; output row y0+rr sums source rows y0+rr .. y0+rr+6,
+    // vertical pass: thread = 4 columns x 8 rows; output row y0+rr sums source rows y0+rr .. y0+rr+6,
     // i.e. four row pairs with the taps aligned for an even or an odd first row
-    const int c = tid & 31, rg = tid >> 5;
+    const int c = tid % CG, rg = tid / CG;
     const int x = tx0 + 4 * c;
     uint8_t *out = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
     const uint32_t we0 = k0 | (k1 << 16), we1 = k2 | (k3 << 16), we2 = k2 | (k1 << 16), we3 = k0;
     const uint32_t wo0 = k0 << 16, wo1 = k1 | (k2 << 16), wo2 = k3 | (k2 << 16), wo3 = k1 | (k0 << 16);
-    uint4 h[5];
+    uint4 h[7];
 #pragma unroll
-    for (int k = 0; k < 5; k++) h[k] = *reinterpret_cast<const uint4 *>(hpair + (rg * 2 + k) * kBW + 4 * c);
+    for (int k = 0; k < 7; k++) h[k] = *reinterpret_cast<const uint4 *>(hpair + (rg * 4 + k) * kBW + 4 * c);
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int y = ty0 + rg * 4 + rr, b = rr >> 1;
+    for (int rr = 0; rr < 8; rr++) {
+        const int y = ty0 + rg * 8 + rr, b = rr >> 1;
         uint32_t packed = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint32_t p0 = q == 0 ? h[b].x : q == 1 ? h[b].y : q == 2 ? h[b].z : h[b].w;
-            const uint32_t p1 = q == 0 ? h[b + 1].x : q == 1 ? h[b + 1].y : q == 2 ? h[b + 1].z : h[b + 1].w;
-            const uint32_t p2 = q == 0 ? h[b + 2].x : q == 1 ? h[b + 2].y : q == 2 ? h[b + 2].z : h[b + 2].w;
-            const uint32_t p3 = q == 0 ? h[b + 3].x : q == 1 ? h[b + 3].y : q == 2 ? h[b + 3].z : h[b + 3].w;
+            const uint32_t p0 = u4_at(h[b], q), p1 = u4_at(h[b + 1], q), p2 = u4_at(h[b + 2], q), p3 = u4_at(h[b + 3], q);
             uint32_t sacc;
             if (rr & 1) sacc = dot2_u16(p3, wo3, dot2_u16(p2, wo2, dot2_u16(p1, wo1, dot2_u16(p0, wo0, 32768u))));
             else sacc = dot2_u16(p3, we3, dot2_u16(p2, we2, dot2_u16(p1, we1, dot2_u16(p0, we0, 32768u))));
@@ -1307,14 +1338,26 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     G.nimg = nimg;
     const LevelGeom &g0 = G.lv[0];
     hipLaunchKernelGGL(k_pyr_copy0, dim3((((g0.w + 15) / 16) * g0.h + 255) / 256, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G_);
-    int rows = (g0.h + 2 * kEdge + 15) / 16;
+    int rows = (g0.h + 2 * kEdge + 31) / 32;
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
-        rows += (g.h + 2 * kEdge + 15) / 16;
+        rows += (g.h + 2 * kEdge + 31) / 32;
         hipLaunchKernelGGL(k_pyr_resize, dim3(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), grid_frames(nimg)), dim3(256),
                            (size_t)g.rs_rows * g.rs_pitch_dw * 4, st, pyr, G, l, xtab, ytab);
     }
-    hipLaunchKernelGGL(k_halo_sides, dim3(rows, nimg), dim3(256), 0, st, pyr, G_);
+    hipLaunchKernelGGL(k_halo4, dim3(rows, nimg), dim3(64), 0, st, pyr, G_);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+// All 19 halo columns of every level (the extraction fills only the 4 it reads).
+int launch_halo_full(hipStream_t st, int nimg, uint8_t *pyr, const Geom &G)
+{
+    int rows = 0;
+    for (int l = 0; l < G.nlevels; l++) rows += (G.lv[l].h + 2 * kEdge + 15) / 16;
+    Geom Gp = G;
+    Gp.nimg = 0;  // plain (block, frame) mapping
+    hipLaunchKernelGGL(k_halo_sides, dim3(rows, nimg), dim3(256), 0, st, pyr, Gp);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
@@ -1384,7 +1427,7 @@ int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, con
     G.nimg = nimg;
     int tiles = 0;
     for (int l = 0; l < G.nlevels; l++) tiles += ((G.lv[l].w + kBW - 1) / kBW) * ((G.lv[l].h + kBH - 1) / kBH);
-    hipLaunchKernelGGL(k_blur, dim3(tiles, grid_frames(nimg)), dim3(256), 0, st, pyr, blur, G);
+    hipLaunchKernelGGL(k_blur, dim3(tiles, grid_frames(nimg)), dim3(kBlurThreads), 0, st, pyr, blur, G);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }

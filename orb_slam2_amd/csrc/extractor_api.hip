@@ -22,6 +22,7 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+int launch_halo_full(hipStream_t st, int nimg, uint8_t *pyr, const Geom &G);
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
                    const Geom &G, const XTab *xtab, const YTab *ytab);
 int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
@@ -78,6 +79,7 @@ struct orbgpu_extractor {
     Geom G;
     int geom_w = 0, geom_h = 0;
     int last_nimg = 0;
+    bool halo_full = false;  // the last extraction's levels carry all 19 halo columns (filled on demand)
     DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab, cell_tab;
     DevBuf st_img, st_kps, st_desc, st_counts;  // staging for the host entry points
     void *h_pinned = nullptr;
@@ -529,6 +531,7 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
     STAGE_MARK(4);
 #undef STAGE_MARK
     e->last_nimg = nimg;
+    e->halo_full = false;
     return ORBGPU_OK;
 }
 
@@ -634,6 +637,11 @@ int orbgpu_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, int3
     if (!dst) return ORBGPU_OK;
     if (dst_stride < lw + 2 * border) return ORBGPU_E_INVALID;
     ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    if (border > 4 && !e->halo_full) {
+        // the extraction fills the halo rows and the 4 halo columns it reads itself; the other 15 on first request
+        if ((rc = launch_halo_full(e->stream, e->last_nimg, (uint8_t *)e->pyr.p, e->G))) return rc;
+        e->halo_full = true;
+    }
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
     ORBGPU_HIP_CHECK(hipMemcpy2D(dst, dst_stride, src - (int64_t)border * pitch - border, pitch, lw + 2 * border,
                                  lh + 2 * border, hipMemcpyDeviceToHost));
