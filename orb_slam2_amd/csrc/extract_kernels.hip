@@ -1162,6 +1162,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     const int slot0 = (blk * 4 + wv) * kDescGroup;
     if (slot0 >= G.total_kp_cap) return;
     const int32_t *sc = sel_count + f * G.nlevels;
+    {
+        // most slots are empty (a level rarely fills its quota): leave on scalar arithmetic alone when none of
+        // this wave's slots holds a keypoint
+        bool any = slot0 == 0;  // the wave of slot 0 also writes the frame's count
+        for (int k = 0; k < G.nlevels; k++) any = any || max(slot0, G.t_kp_off[k]) < min(slot0 + kDescGroup, G.t_kp_off[k] + sc[k]);
+        if (!any) return;
+    }
 
     // lane j < kDescGroup: geometry of slot slot0 + j (invalid slots compute on pixel (19, 19) of
     // level 0 and store nothing); every table below is read with uniform, independent loads
@@ -1289,6 +1296,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 #pragma unroll
         for (int m = 0; m < 6; m++) pre[m] = *reinterpret_cast<const uint32_t *>(c + srow[m] * pitch + 4 * scol[m]);
     }
+    // the pattern as floats, once per wave
+    float px0[4], py0[4], px1[4], py1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { px0[k] = (float)pt[k].x; py0[k] = (float)pt[k].y; px1[k] = (float)pt[k].z; py1[k] = (float)pt[k].w; }
     for (int j = 0; j < kDescGroup; j++) {
 #pragma unroll
         for (int m = 0; m < 6; m++) pw[srow[m] * (kBPitch / 4) + scol[m]] = pre[m];
@@ -1306,7 +1317,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         int tap0[4], tap1[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float x0 = (float)pt[k].x, y0 = (float)pt[k].y, x1 = (float)pt[k].z, y1 = (float)pt[k].w;
+            const float x0 = px0[k], y0 = py0[k], x1 = px1[k], y1 = py1[k];
             const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
             const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
