@@ -487,16 +487,32 @@ __global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
     uint32_t qd[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) qd[k] = live ? P.QD[(size_t)i * 8 + k] : 0u;
+    // The walk is latency-bound (few waves, dependent loads), so every load is issued as early as its address is
+    // known: the bounds of the next column's run while the current one is walked, the next entry's record and the
+    // current entry's descriptor before the gates are evaluated.
     int col = live ? c0 : c1 + 1, k = 0, e = 0;
+    int kn = 0, en = 0;  // run of column `col`
+    if (col <= c1) {
+        kn = P.cell_start[col * ORBGPU_GRID_ROWS + r0];
+        en = P.cell_start[col * ORBGPU_GRID_ROWS + r1 + 1];
+    }
+    int4 rec = make_int4(0, 0, 0, 0);
     while (true) {
         if (k >= e) {  // next grid column of the window
             if (col > c1) break;
-            k = P.cell_start[col * ORBGPU_GRID_ROWS + r0];
-            e = P.cell_start[col * ORBGPU_GRID_ROWS + r1 + 1];
+            k = kn;
+            e = en;
             col++;
+            if (col <= c1) {
+                kn = P.cell_start[col * ORBGPU_GRID_ROWS + r0];
+                en = P.cell_start[col * ORBGPU_GRID_ROWS + r1 + 1];
+            }
+            if (k < e) rec = P.grec[k];
             continue;
         }
-        const int4 rec = P.grec[k];
+        const uint4 d0 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k];
+        const uint4 d1 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k + 1];
+        const int4 rec_next = P.grec[min(k + 1, e - 1)];
         const int oct = rec.z, t = rec.w;
         bool ok = true;
         if (check) {
@@ -509,10 +525,9 @@ __global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
             if (ok && mode < 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
             if (ok && mode == 6 && A.chi2_gate) ok = reprojection_gate(A, P, q, rec, t);
         }
+        rec = rec_next;
         uint32_t key = kNoCand;
         if (ok) {
-            const uint4 d0 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k];
-            const uint4 d1 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k + 1];
             const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
                              __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
             if (cand_useful(A, dist)) {
