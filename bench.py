@@ -85,7 +85,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     B = args.batch
-    frames = synth.sequence(W, H, B, seed=1 + rank, step=STEP)
+    frames = synth.sequence(W, H, B, seed=1 + rank, step=STEP, per_frame_density=True)
     d_imgs = torch.from_numpy(frames).to(dev)
 
     # S independent sub-pipelines (own extractor + matcher handle, own HIP stream), each taking B/S

@@ -8,8 +8,10 @@ matched with a known ground-truth shift.
 import numpy as np
 
 
-def _canvas(w, h, seed, n_shapes):
+def _canvas(w, h, seed, n_shapes, smax=None):
     rng = np.random.default_rng(seed)
+    if smax is None:
+        smax = max(8, min(w, h) // 6)
     img = np.full((h, w), 128, np.float32)
     # low-frequency shading so flat regions are not perfectly flat
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
@@ -17,9 +19,9 @@ def _canvas(w, h, seed, n_shapes):
     for _ in range(n_shapes):
         g = float(rng.integers(0, 256))
         cx = int(rng.integers(0, w)); cy = int(rng.integers(0, h))
-        s = int(rng.integers(4, max(8, min(w, h) // 6)))
+        s = int(rng.integers(4, smax))
         if rng.random() < 0.6:
-            s2 = int(rng.integers(4, max(8, min(w, h) // 6)))
+            s2 = int(rng.integers(4, smax))
             img[max(cy - s2, 0):cy + s2, max(cx - s, 0):cx + s] = g
         else:
             y0, y1 = max(cy - s, 0), min(cy + s + 1, h)
@@ -33,13 +35,19 @@ def _canvas(w, h, seed, n_shapes):
     return img
 
 
-def sequence(w, h, n_frames, seed=1, n_shapes=None, noise=3.0, step=(2, 1)):
-    """Return uint8 array [n_frames, h, w]; frame k = canvas crop shifted by k*step."""
+def sequence(w, h, n_frames, seed=1, n_shapes=None, noise=3.0, step=(2, 1), per_frame_density=False):
+    """Return uint8 array [n_frames, h, w]; frame k = canvas crop shifted by k*step.
+    n_shapes counts the shapes drawn on the whole canvas; with per_frame_density it is the number per frame-sized
+    area instead (long sequences travel over a canvas many frames large and would otherwise thin out)."""
     if n_shapes is None:
         n_shapes = max(60, (w * h) // 768)
     mx = abs(step[0]) * n_frames + 8
     my = abs(step[1]) * n_frames + 8
-    can = _canvas(w + mx, h + my, seed, n_shapes)
+    smax = None
+    if per_frame_density:
+        n_shapes = int(round(n_shapes * float((w + mx) * (h + my)) / float(w * h)))
+        smax = max(8, min(w, h) // 6)  # shape sizes of a frame-sized canvas
+    can = _canvas(w + mx, h + my, seed, n_shapes, smax)
     rng = np.random.default_rng(seed + 7919)
     out = np.empty((n_frames, h, w), np.uint8)
     for k in range(n_frames):
