@@ -426,10 +426,122 @@ __device__ __forceinline__ void scan_segment(const MatchArgs &A, const PairCtx &
     if (DYN) top2_wave_reduce(t2);
 }
 
-// Segment modes (SearchByBoW, SearchForTriangulation): a wave scans the vocabulary-node segments of two queries,
-// one after the other, and leaves each query's kTopK best candidates in key order.
+// Two queries per wave, one per 32-lane half: the window setup and the final
+// ordering of the cache are shared by both, and most windows hold fewer than 32
+// candidates.  Window c0 .. c0+ncols-1 x r0 .. r1 (ncols <= 32; 0 = nothing to
+// scan); wl[33], ws[32] and wk[kTopK] belong to this half.
+__device__ __forceinline__ void scan_window_half(const MatchArgs &A, const PairCtx &P, int i, const orbgpu_wquery &q, int c0,
+                                                 int ncols, int r0, int r1, int *wl, int *ws, unsigned long long *wk, int &npass)
+{
+    const int lane = lane_id(), sub = lane & 31, hs = lane & 32, mode = A.mode;
+    const float r = q.r;
+    npass = 0;
+    int nk = 0;  // valid entries in wk
+    int s = 0, len = 0;
+    if (sub < ncols) {
+        s = P.cell_start[(c0 + sub) * ORBGPU_GRID_ROWS + r0];
+        len = P.cell_start[(c0 + sub) * ORBGPU_GRID_ROWS + r1 + 1] - s;
+    }
+    int inc = len;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int t = __shfl_up(inc, o, 32);
+        if (sub >= o) inc += t;
+    }
+    const int total = __shfl(inc, 31, 32);
+    const int tmax = max(total, __shfl_xor(total, 32));
+    if (tmax == 0) return;
+    ws[sub] = s;
+    wl[sub + 1] = inc;
+    if (sub == 0) wl[0] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const bool check = (q.minLevel > 0) || (q.maxLevel >= 0);
+    uint32_t qd[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) qd[k] = total ? P.QD[(size_t)i * 8 + k] : 0u;
+    for (int base = 0; base < tmax; base += 32) {
+        const int j = base + sub;
+        unsigned long long key = kNoKey;
+        if (j < total) {
+            int lo = 0, hi = ncols - 1;  // column c with wl[c] <= j < wl[c+1]
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (wl[mid] <= j) lo = mid; else hi = mid - 1;
+            }
+            const int k = ws[lo] + (j - wl[lo]);
+            const int4 rec = P.grec[k];
+            const int oct = rec.z, t = rec.w;
+            bool ok = true;
+            if (check) {
+                if (oct < q.minLevel) ok = false;
+                if (q.maxLevel >= 0 && oct > q.maxLevel) ok = false;
+            }
+            if (ok && !(fabsf(__fsub_rn(__int_as_float(rec.x), q.u)) < r && fabsf(__fsub_rn(__int_as_float(rec.y), q.v)) < r)) ok = false;
+            if (ok && mode != 3) {
+                if (P.OCC && P.OCC[t]) ok = false;
+                if (ok && mode < 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
+                if (ok && mode == 6 && A.chi2_gate) ok = reprojection_gate(A, P, q, rec, t);
+            }
+            if (ok) {
+                // the descriptor is fetched only for entries inside the window and the level range (a minority)
+                const uint4 d0 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k];
+                const uint4 d1 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k + 1];
+                const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
+                                 __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
+                if (cand_useful(A, dist)) key = ((unsigned long long)dist << 40) | ((unsigned long long)j << 20) | (unsigned)t;
+            }
+        }
+        // unordered cache, as in scan_window<false>, with every cross-lane step confined to the half
+        const uint32_t vh = (uint32_t)(__ballot(key != kNoKey) >> hs);
+        const int nv = __popc(vh);
+        npass += nv;
+        const bool fits = nk + nv <= kTopK;
+        if (fits) {
+            if (key != kNoKey) wk[nk + __popc(vh & ((1u << sub) - 1u))] = key;
+            nk += nv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (__ballot(!fits) != 0ull) {
+            bool active = !fits;
+            uint32_t k32 = (active && key != kNoKey) ? ((uint32_t)(key >> 40) << 22) | (uint32_t)((key >> 20) & 0xFFFFFu) : 0xFFFFFFFFu;
+            for (int rnd = 0; rnd < 32; rnd++) {
+                uint32_t m = k32;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+                if (m == 0xFFFFFFFFu) active = false;
+                if (__ballot(active) == 0ull) break;
+                const uint32_t eq = (uint32_t)(__ballot(active && k32 == m) >> hs);
+                const int src = hs + (eq ? __ffs((int)eq) - 1 : 0);
+                const unsigned long long mk = shfl_u64(key, src);
+                if (active && lane == src) k32 = 0xFFFFFFFFu;
+                // largest cached key and its slot (used once the cache is full)
+                unsigned long long mx = sub < kTopK ? wk[sub] : 0ull;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) mx = max(mx, shfl_xor_u64(mx, o));
+                mx = shfl_u64(mx, hs);
+                const uint32_t sl = (uint32_t)(__ballot(sub < kTopK && wk[sub] == mx) >> hs);
+                if (active) {
+                    if (nk < kTopK) {
+                        if (sub == 0) wk[nk] = mk;
+                        nk++;
+                    } else if (mk >= mx) {
+                        active = false;  // later candidates of this chunk are larger still
+                    } else if (sub == 0) {
+                        wk[__ffs((int)sl) - 1] = mk;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+// Two queries per wave: the segment modes (SearchByBoW, SearchForTriangulation) always, the window modes for small
+// launches (a frame or two: the candidates of a window are spread over 32 lanes, which keeps the latency of a
+// single frame low; large batches use k_window_topk_lanes).
 __global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
 {
+    __shared__ int wl[4][66], ws[4][64];
     __shared__ unsigned long long wk[4][2][kTopK];
     __shared__ uint32_t wp[4][2][kTopK];
     const int pair = blockIdx.y, w = threadIdx.x >> 6, lane = lane_id(), sub = lane & 31, half = lane >> 5;
@@ -439,14 +551,40 @@ __global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
     const bool inq = i < P.nq;
     if (sub < kTopK) wk[w][half][sub] = kNoKey;
     __builtin_amdgcn_wave_barrier();
+    const orbgpu_wquery q = P.Q[inq ? i : i0];
     int npass = 0;
-    for (int h = 0; h < 2 && i0 + h < P.nq; h++) {
-        const orbgpu_wquery qh = P.Q[i0 + h];
-        Top2 t2;
-        int np = 0;
-        if (qh.flags & 1) scan_segment<false>(A, P, i0 + h, qh, wk[w][h], t2, np);
-        if (half == h) npass = np;
-        __builtin_amdgcn_wave_barrier();
+    if (A.mode == 4 || A.mode == 5) {
+        // vocabulary-node segments: the full-wave scan, one query after the other
+        for (int h = 0; h < 2 && i0 + h < P.nq; h++) {
+            const orbgpu_wquery qh = P.Q[i0 + h];
+            Top2 t2;
+            int np = 0;
+            if (qh.flags & 1) scan_segment<false>(A, P, i0 + h, qh, wk[w][h], t2, np);
+            if (half == h) npass = np;
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // window of this half's query (Frame::GetFeaturesInArea, src/Frame.cc:402-420)
+        const float r = q.r;
+        const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
+        const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
+        const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
+        const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
+        const bool live = inq && (q.flags & 1) && !(c0 >= ORBGPU_GRID_COLS || c1 < 0 || r0 >= ORBGPU_GRID_ROWS || r1 < 0);
+        const int ncols = live ? c1 - c0 + 1 : 0;
+        if (__ballot(ncols > 32) == 0ull) {
+            scan_window_half(A, P, i, q, c0, ncols, r0, r1, wl[w] + 33 * half, ws[w] + 32 * half, wk[w][half], npass);
+        } else {
+            // a window wider than 32 grid columns: the full-wave scan, one query after the other
+            for (int h = 0; h < 2 && i0 + h < P.nq; h++) {
+                const orbgpu_wquery qh = P.Q[i0 + h];
+                Top2 t2;
+                int np = 0;
+                if (qh.flags & 1) scan_window<false>(A, P, 0, i0 + h, qh, wl[w], ws[w], wk[w][h], t2, np);
+                if (half == h) npass = np;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
     __builtin_amdgcn_wave_barrier();
     // the cache is a set of distinct keys: rank = position in ascending key order
@@ -812,8 +950,11 @@ __global__ __launch_bounds__(256) void k_shift_queries(const orbgpu_keypoint *__
 int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
 {
     if (A.mode != 4 && A.mode != 5) hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
-    if (A.mode == 4 || A.mode == 5) hipLaunchKernelGGL(k_window_topk, dim3((A.q_cap + 7) / 8, npairs), dim3(256), 0, st, A);
-    else hipLaunchKernelGGL(k_window_topk_lanes, dim3((A.q_cap + 63) / 64, npairs), dim3(64), 0, st, A);
+    // a lane per query pays once there are enough queries to fill the chip; below that the half-wave scan is quicker
+    if (A.mode == 4 || A.mode == 5 || (int64_t)A.q_cap * npairs < 65536)
+        hipLaunchKernelGGL(k_window_topk, dim3((A.q_cap + 7) / 8, npairs), dim3(256), 0, st, A);
+    else
+        hipLaunchKernelGGL(k_window_topk_lanes, dim3((A.q_cap + 63) / 64, npairs), dim3(64), 0, st, A);
     // selection state in LDS when it fits (6 words per query + 1 per train keypoint)
     const size_t state = (6 * (size_t)A.q_cap + (size_t)A.t_cap) * 4;
     const int lds_state = state <= 48 * 1024;

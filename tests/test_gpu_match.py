@@ -372,3 +372,48 @@ def test_bruteforce_100k_properties(matcher):
         assert b1[i] == ORBmatcher.DescriptorDistance(Q[i], T[bi[i]])
     si, s1, s2 = matcher.BruteForce(Q[:5000], Q[:5000])
     assert np.array_equal(si, np.arange(5000)) and (s1 == 0).all() and (s2 > 0).all()
+
+
+@pytest.mark.parametrize("mode,th", [(1, 15.0), (0, 9.0), (2, 30.0)])
+def test_batch_device_many_pairs(oracle, frames, mode, th):
+    """64 pairs in one launch: batches of this size use the lane-per-query scan (single calls use the half-wave
+    scan), both must give the reference's result.  The pairs differ in query subset, radius and occupancy."""
+    from orb_slam2_amd import api
+    from hiputil import Hip
+    m = api.ORBmatcher(0.8, True)
+    sc = oracle.tables(oracle.make_params(1000))["scale"]
+    b = _bounds()
+    npairs, qcap, tcap = 64, 1100, 1100
+    rng = np.random.default_rng(100 + mode)
+    Q = np.zeros((npairs, qcap), api.WQUERY_DTYPE); QD = np.zeros((npairs, qcap, 32), np.uint8)
+    K2 = np.zeros((npairs, tcap), api.KEYPOINT_DTYPE); D2 = np.zeros((npairs, tcap, 32), np.uint8)
+    OCC = np.zeros((npairs, tcap), np.uint8)
+    NQ = np.zeros(npairs, np.int32); N2 = np.zeros(npairs, np.int32)
+    refs = []
+    for p in range(npairs):
+        (ka, da), (kb, db) = frames[p % 2], frames[p % 2 + 1]
+        keep = np.sort(rng.choice(len(ka), size=int(rng.integers(1, len(ka) + 1)), replace=False)) if p else np.arange(len(ka))
+        q = api.shift_queries(ka[keep], -2.0, -1.0, th * (0.5 + p / 40.0), sc, b)
+        if mode == 0:
+            q["maxLevel"] = ka["octave"][keep]
+        if p == 5:
+            q = q[:0]; keep = keep[:0]  # a pair without queries
+        occ = (rng.random(len(kb)) < 0.15).astype(np.uint8) if p % 3 == 0 else np.zeros(len(kb), np.uint8)
+        Q[p, :len(q)] = q; QD[p, :len(q)] = da[keep]; NQ[p] = len(q)
+        K2[p, :len(kb)] = kb; D2[p, :len(kb)] = db; N2[p] = len(kb); OCC[p, :len(kb)] = occ
+        refs.append(oracle.search_by_projection(mode, q.view(oracle.WQUERY_DTYPE), da[keep], kb.view(oracle.KEYPOINT_DTYPE), db, b,
+                                                occupied=occ, th_dist=100, nnratio=0.8, checkOri=True))
+    hip = Hip()
+    try:
+        dQ, dQD, dNQ, dK2, dD2, dN2, dOCC = [hip.upload(a) for a in (Q, QD, NQ, K2, D2, N2, OCC)]
+        dA = hip.alloc(npairs * tcap * 4); dNM = hip.alloc(npairs * 4)
+        m.search_by_projection_batch_device(mode, npairs, dQ.value, dQD.value, dNQ.value, qcap, dK2.value, dD2.value, dN2.value, tcap,
+                                            b, dA.value, dNM.value, th_dist=100, d_occupied=dOCC.value)
+        m.sync()
+        A = hip.download(dA, (npairs, tcap), np.int32); NM = hip.download(dNM, npairs, np.int32)
+    finally:
+        hip.free()
+    for p, (rn, rassign) in enumerate(refs):
+        assert NM[p] == rn, "pair %d" % p
+        assert np.array_equal(A[p, :N2[p]], rassign), "pair %d" % p
+    assert NM.sum() > 5000
