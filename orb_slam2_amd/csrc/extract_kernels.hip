@@ -1162,6 +1162,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     const int slot0 = (blk * 4 + wv) * kDescGroup;
     if (slot0 >= G.total_kp_cap) return;
     const int32_t *sc = sel_count + f * G.nlevels;
+#ifdef ORBGPU_STAMPS
+    unsigned long long dstamp_prev = __builtin_readcyclecounter();
+    const unsigned dstamp_id = kStampWgs / 2 + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));  // upper half: FAST uses the lower
+#define ORB_DSTAMP(k_) do { if ((threadIdx.x & 63) == 0 && dstamp_id < (unsigned)kStampWgs) { const unsigned long long now_ = __builtin_readcyclecounter(); g_fast_stamps[dstamp_id * 8 + k_] += (unsigned)(now_ - dstamp_prev); dstamp_prev = now_; } } while (0)
+#else
+#define ORB_DSTAMP(k_) do { } while (0)
+#endif
     {
         // most slots are empty (a level rarely fills its quota): leave on scalar arithmetic alone when none of
         // this wave's slots holds a keypoint
@@ -1212,6 +1219,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         my_off += my_y * my_pitch + my_x;
     }
     if (__ballot(my_valid && lane < kDescGroup) == 0) return;
+    ORB_DSTAMP(1);
     const uint8_t *fpyr = pyr + (int64_t)f * G.pyr_frame_bytes, *fblur = blur + (int64_t)f * G.pyr_frame_bytes;
 
     // ---- stage A: m10 = sum u*I, m01 = sum v*I over the disc (:85-130) -----------------
@@ -1257,6 +1265,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         if (lane == j) { my_m10 = m10; my_m01 = m01; }
     }
 
+    ORB_DSTAMP(2);
     // ---- stage B: orientation, once per group ---------------------------------------------
     const float my_angle = fast_atan2_deg((float)my_m01, (float)my_m10);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
@@ -1275,6 +1284,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         kps[(int64_t)f * capacity + my_oi] = k;
     }
 
+    ORB_DSTAMP(3);
     // ---- stage C: steered BRIEF on the blurred level (:142-191) -----------------------------
     char4 pt[4];
 #pragma unroll
@@ -1335,6 +1345,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             reinterpret_cast<uint64_t *>(desc + ((int64_t)f * capacity + oi) * 32)[lane] = w;
         }
     }
+    ORB_DSTAMP(4);
 }
 
 // ---------------------------------------------------------------------------
