@@ -73,7 +73,7 @@ def brute(n=100000):
         m.sync()
     dt = timed(step, 5)
     pairs = float(n) * n
-    lanes_clk = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock
+    lanes_clk = 256 * 4 * 16 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock: a wave64 integer instruction issues over 4 cycles
     print(json.dumps({"config": "brute force %dk x %dk x 256 bit" % (n // 1000, n // 1000), "ms": dt * 1e3,
                       "pairs_per_s": pairs / dt, "valu_util_at_16_ops_per_pair": 16 * pairs / dt / lanes_clk,
                       "hbm_GBps": (64.0 * n + 12.0 * n) / dt / 1e9}), flush=True)
