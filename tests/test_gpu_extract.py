@@ -249,3 +249,22 @@ def test_4k_frame_8000_features(oracle):
     assert np.array_equal(ex.pyramid_level(0), img)
     top = ex.pyramid_level(7, border=19)
     assert np.array_equal(top, np.pad(top[19:-19, 19:-19], 19, mode="reflect"))
+
+
+def test_halo_columns_are_completed_on_request(oracle):
+    """The extraction writes the 19 halo rows and 4 halo columns per side; the other 15 columns are filled when a
+    level is first asked for with its border -- for the images of the latest extraction, not an earlier one."""
+    seq = synth.sequence(640, 480, 3, seed=17)
+    ex = _mk(640, 480, 1000, max_batch=2)
+    oe = oracle.Extractor(1000)
+    for img in (seq[0], seq[1]):
+        ex(img)
+        oe.extract(img)
+        for border in (3, 4, 19, 7):
+            for l in (0, 3, 7):
+                assert np.array_equal(ex.pyramid_level(l, border=border), oracle.border101(oe.level(l), border)), (border, l)
+    # a batch: every frame of it
+    ex.extract_batch(seq[1:3])
+    for f in (0, 1):
+        oe.extract(seq[1 + f])
+        assert np.array_equal(ex.pyramid_level(2, frame=f, border=19), oracle.border101(oe.level(2), 19))
