@@ -268,3 +268,26 @@ def test_halo_columns_are_completed_on_request(oracle):
     for f in (0, 1):
         oe.extract(seq[1 + f])
         assert np.array_equal(ex.pyramid_level(2, frame=f, border=19), oracle.border101(oe.level(2), 19))
+
+
+def test_two_handles_from_two_threads(oracle):
+    """The reference extracts the left and the right image in two threads on two extractor instances
+    (src/Frame.cc:78-81): two handles used concurrently give what each gives alone."""
+    import threading
+    L, R, _ = synth.stereo_pair(752, 480, seed=3)
+    exL, exR = _mk(752, 480, 1200), _mk(752, 480, 1200)
+    refL, refR = exL(L), exR(R)
+    out = {}
+
+    def work(name, ex, img):
+        res = []
+        for _ in range(20):
+            res.append(ex(img))
+        out[name] = res
+
+    tl = threading.Thread(target=work, args=("L", exL, L)); tr = threading.Thread(target=work, args=("R", exR, R))
+    tl.start(); tr.start(); tl.join(); tr.join()
+    for k, d in out["L"]:
+        assert np.array_equal(k, refL[0]) and np.array_equal(d, refL[1])
+    for k, d in out["R"]:
+        assert np.array_equal(k, refR[0]) and np.array_equal(d, refR[1])
