@@ -259,35 +259,34 @@ constexpr int kFastQuad = 4;  // consecutive cells per workgroup in batch launch
 // One FAST cell: geometry of :1043-1072 and where its pixels lie.
 struct FastCell {
     int state;  // 0: past the last cell, 1: skipped by the rules of :1053 / :1068 (count 0), 2: to be searched
-    int l, ci, ci_i, ci_j, cw, ch, ndw, pitch;
+    int l, ci, ci_i, ci_j, cw, ch, ndw, pitch, mdiv, mdivg;
     const uint8_t *src;  // the byte left of the cell image's first pixel
 };
 
+// The host tabulates the geometry of every cell (eight words: level | row << 8 | column << 20; state | cw << 8 |
+// ch << 16; iniX | iniY << 16; ceil(2^20 / interior width); ceil(2^20 / pixel groups per row)).
 __device__ __forceinline__ FastCell fast_cell_info(const uint8_t *__restrict__ pyr, const Geom &G, const uint32_t *__restrict__ cell_tab, int f,
                                                    int cell)
 {
     FastCell c;
     c.state = 0;
     if (cell >= G.total_cells) return c;
-    // cell_tab: level | cell row << 8 | cell column << 20
-    const uint32_t ct = cell_tab[cell];
-    c.l = ct & 0xFF; c.ci_i = (ct >> 8) & 0xFFF; c.ci_j = ct >> 20;
+    const uint4 t0 = reinterpret_cast<const uint4 *>(cell_tab)[2 * (size_t)cell];
+    c.l = t0.x & 0xFF; c.ci_i = (t0.x >> 8) & 0xFFF; c.ci_j = t0.x >> 20;
     const LevelGeom &g = G.lv[c.l];
     c.ci = cell - g.cell_off;
-    const int maxBX = g.w - kMinBorder, maxBY = g.h - kMinBorder;
-    const int iniY = kMinBorder + c.ci_i * g.hCell, iniX = kMinBorder + c.ci_j * g.wCell;
-    c.state = 1;
-    // skip rules of :1053 and :1068 (the column rule uses 6, the row rule 3)
-    if (iniY >= maxBY - 3 || iniX >= maxBX - 6) return c;
-    c.cw = min(iniX + g.wCell + 6, maxBX) - iniX;
-    c.ch = min(iniY + g.hCell + 6, maxBY) - iniY;
-    if (c.cw <= 6 || c.ch <= 6) return c;
+    c.state = t0.y & 0xFF;
+    if (c.state != 2) return c;
+    c.cw = (t0.y >> 8) & 0xFF;
+    c.ch = t0.y >> 16;
+    const int iniX = t0.z & 0xFFFF, iniY = t0.z >> 16;
+    c.mdiv = (int)t0.w;
+    c.mdivg = (int)cell_tab[8 * (size_t)cell + 4];
     // The cell image goes one byte into the tile rows (tile byte 1 + x of row y = cell image (x, y)): the interior,
     // cell image column 3, then starts on a dword boundary.  The copy reads dwords at byte addresses.
     c.ndw = (c.cw + 4) >> 2;
     c.pitch = g.pitch;
     c.src = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)iniY * g.pitch + (iniX - 1);
-    c.state = 2;
     return c;
 }
 
@@ -380,11 +379,11 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     // min / max / subtract and the verdicts are the sign bits.  Survivors go to a dense pixel queue for the
     // arc evaluation.
     const int t = G.minTh;
-    const int mdiv = ((1 << 20) + wi - 1) / wi;
+    const int mdiv = cu.mdiv;
     const uint8_t *t0 = cur + 1;  // pixel (x, y) of the cell image is t0[y * kTP + x]
     const uint32_t *tile32 = reinterpret_cast<const uint32_t *>(cur);
     const int ngx = (wi + 3) >> 2, ngroups = ngx * hi;  // groups of four interior pixels = dwords 1 .. ngx of a tile row
-    const int mdivg = ((1 << 20) + ngx - 1) / ngx;
+    const int mdivg = cu.mdivg;
     {
         const short2v tt = __builtin_bit_cast(short2v, (uint32_t)t * 0x10001u);
         constexpr int RP = kTP / 4;

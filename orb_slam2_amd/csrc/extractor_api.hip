@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "orbgpu_internal.h"
@@ -312,12 +313,34 @@ static int set_geometry(orbgpu_extractor *e, int w, int h)
     if ((rc = e->xtab.ensure(xt.size() * sizeof(XTab) + 16))) return rc;
     if ((rc = e->ytab.ensure(yt.size() * sizeof(YTab) + 16))) return rc;
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
-    // FAST cell table: level | cell row << 8 | cell column << 20
-    std::vector<uint32_t> ctab((size_t)G.total_cells);
-    for (int l = 0; l < G.nlevels; l++)
-        for (int i = 0; i < G.lv[l].nRows; i++)
-            for (int j = 0; j < G.lv[l].nCols; j++)
-                ctab[(size_t)G.lv[l].cell_off + (size_t)i * G.lv[l].nCols + j] = (uint32_t)l | ((uint32_t)i << 8) | ((uint32_t)j << 20);
+    // FAST cell table, eight words per cell (the geometry of src/ORBextractor.cc:1043-1072, so that the kernel needs
+    // no divisions): level | cell row << 8 | cell column << 20; state | cw << 8 | ch << 16 (state 1: skipped by the
+    // rules of :1053 / :1068, 2: searched; cw x ch = cell image incl. the 3 px apron); iniX | iniY << 16;
+    // ceil(2^20 / interior width); ceil(2^20 / groups of four interior pixels per row); three unused
+    std::vector<uint32_t> ctab((size_t)G.total_cells * 8, 0u);
+    for (int l = 0; l < G.nlevels; l++) {
+        const LevelGeom &g = G.lv[l];
+        const int maxBX = g.w - kMinBorder, maxBY = g.h - kMinBorder;
+        for (int i = 0; i < g.nRows; i++)
+            for (int j = 0; j < g.nCols; j++) {
+                uint32_t *r = &ctab[((size_t)g.cell_off + (size_t)i * g.nCols + j) * 8];
+                r[0] = (uint32_t)l | ((uint32_t)i << 8) | ((uint32_t)j << 20);
+                const int iniY = kMinBorder + i * g.hCell, iniX = kMinBorder + j * g.wCell;
+                int state = 1, cw = 0, ch = 0;
+                if (!(iniY >= maxBY - 3 || iniX >= maxBX - 6)) {
+                    cw = std::min(iniX + g.wCell + 6, maxBX) - iniX;
+                    ch = std::min(iniY + g.hCell + 6, maxBY) - iniY;
+                    if (cw > 6 && ch > 6) state = 2;
+                }
+                r[1] = (uint32_t)state | ((uint32_t)cw << 8) | ((uint32_t)ch << 16);
+                r[2] = (uint32_t)iniX | ((uint32_t)iniY << 16);
+                if (state == 2) {
+                    const int wi = cw - 6, ngx = (wi + 3) >> 2;
+                    r[3] = (uint32_t)(((1 << 20) + wi - 1) / wi);
+                    r[4] = (uint32_t)(((1 << 20) + ngx - 1) / ngx);
+                }
+            }
+    }
     if ((rc = e->cell_tab.ensure(ctab.size() * 4 + 16))) return rc;
     ORBGPU_HIP_CHECK(hipMemcpy(e->cell_tab.p, ctab.data(), ctab.size() * 4, hipMemcpyHostToDevice));
     ORBGPU_HIP_CHECK(hipMemcpy(e->xtab.p, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice));
