@@ -5,6 +5,8 @@
 //   pyr_copy0 -> pyr_resize (levels 1..L-1, dependent chain) -> fast_cells ->
 //   octree -> blur -> describe
 // Reference lines are relative to /root/reference/src/ORB_SLAM2/.
+#include <vector>
+
 #include "orbgpu_internal.h"
 
 namespace orbgpu {
@@ -1007,23 +1009,18 @@ __device__ __forceinline__ uint32_t u4_at(const uint4 &v, int q) { return q == 0
 
 // One wave per 64 x 32 tile: narrow tiles waste few lanes on the level widths, and the 19 x 16 horizontal tasks
 // fill five passes of the wave almost completely.
-__global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G)
+__global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G,
+                                                      const uint32_t *__restrict__ tile_tab)
 {
     // horizontal sums (16 bit) of source rows 2i and 2i+1 share a dword: hpair[i][x] = h[2i][x] | h[2i+1][x] << 16
     __shared__ __align__(16) uint32_t hpair[(kBH + 6) / 2 * kBW];
     int f, t;
     if (!frame_block(G.nimg, &f, &t)) return;
     const int tid = threadIdx.x;
-    int l = 0;
-    while (true) {
-        const int n = ((G.lv[l].w + kBW - 1) / kBW) * ((G.lv[l].h + kBH - 1) / kBH);
-        if (t < n) break;
-        t -= n;
-        if (++l >= G.nlevels) return;
-    }
-    const LevelGeom &g = G.lv[l];
-    const int tilesX = (g.w + kBW - 1) / kBW;
-    const int ty0 = (t / tilesX) * kBH, tx0 = (t % tilesX) * kBW;
+    // the host tabulates the tiles: level | tile column << 8 | tile row << 20 (no searches or divisions here)
+    const uint32_t tt = tile_tab[t];
+    const LevelGeom &g = G.lv[tt & 0xFF];
+    const int ty0 = (int)(tt >> 20) * kBH, tx0 = (int)((tt >> 8) & 0xFFF) * kBW;
     // taps (:1487, cv::GaussianBlur 7x7 sigma 2 in 8-bit fixed point) as byte / 16-bit dot-product operands
     const uint32_t k0 = 18, k1 = 34, k2 = G.gauss_variant ? 48 : 49, k3 = G.gauss_variant ? 56 : 55;
     const uint32_t klo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), khi = k2 | (k1 << 8) | (k0 << 16);
@@ -1442,13 +1439,21 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     return ORBGPU_OK;
 }
 
-int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G_)
+// Tile table of the blur: level | tile column << 8 | tile row << 20 for every kBW x kBH tile of every level.
+int blur_tile_table(const Geom &G, std::vector<uint32_t> *tab)
+{
+    tab->clear();
+    for (int l = 0; l < G.nlevels; l++)
+        for (int ty = 0; ty < (G.lv[l].h + kBH - 1) / kBH; ty++)
+            for (int tx = 0; tx < (G.lv[l].w + kBW - 1) / kBW; tx++) tab->push_back((uint32_t)l | ((uint32_t)tx << 8) | ((uint32_t)ty << 20));
+    return (int)tab->size();
+}
+
+int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G_, const uint32_t *tile_tab, int ntiles)
 {
     Geom G = G_;
     G.nimg = nimg;
-    int tiles = 0;
-    for (int l = 0; l < G.nlevels; l++) tiles += ((G.lv[l].w + kBW - 1) / kBW) * ((G.lv[l].h + kBH - 1) / kBH);
-    hipLaunchKernelGGL(k_blur, dim3(tiles, grid_frames(nimg)), dim3(kBlurThreads), 0, st, pyr, blur, G);
+    hipLaunchKernelGGL(k_blur, dim3(ntiles, grid_frames(nimg)), dim3(kBlurThreads), 0, st, pyr, blur, G, tile_tab);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }

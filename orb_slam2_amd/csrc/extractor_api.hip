@@ -30,7 +30,8 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
                 int32_t *cell_counts);
 int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
                   QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status);
-int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G);
+int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G, const uint32_t *tile_tab, int ntiles);
+int blur_tile_table(const Geom &G, std::vector<uint32_t> *tab);
 int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t *blur, const Geom &G, const uint32_t *sel,
                     const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
                     int capacity, int32_t *status);
@@ -81,7 +82,8 @@ struct orbgpu_extractor {
     int geom_w = 0, geom_h = 0;
     int last_nimg = 0;
     bool halo_full = false;  // the last extraction's levels carry all 19 halo columns (filled on demand)
-    DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab, cell_tab;
+    DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab, cell_tab, blur_tab;
+    int blur_tiles = 0;
     DevBuf st_img, st_kps, st_desc, st_counts;  // staging for the host entry points
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
@@ -343,6 +345,10 @@ static int set_geometry(orbgpu_extractor *e, int w, int h)
     }
     if ((rc = e->cell_tab.ensure(ctab.size() * 4 + 16))) return rc;
     ORBGPU_HIP_CHECK(hipMemcpy(e->cell_tab.p, ctab.data(), ctab.size() * 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t> btab;
+    e->blur_tiles = blur_tile_table(G, &btab);
+    if ((rc = e->blur_tab.ensure(btab.size() * 4 + 16))) return rc;
+    ORBGPU_HIP_CHECK(hipMemcpy(e->blur_tab.p, btab.data(), btab.size() * 4, hipMemcpyHostToDevice));
     ORBGPU_HIP_CHECK(hipMemcpy(e->xtab.p, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice));
     ORBGPU_HIP_CHECK(hipMemcpy(e->ytab.p, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice));
     e->G = G;
@@ -414,7 +420,7 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e)
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DevBuf *bufs[] = {&e->pyr, &e->blur, &e->slots, &e->cell_counts, &e->cand, &e->nodes, &e->scratch, &e->sel, &e->sel_count,
-                      &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->cell_tab, &e->st_img, &e->st_kps, &e->st_desc, &e->st_counts};
+                      &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->cell_tab, &e->blur_tab, &e->st_img, &e->st_kps, &e->st_desc, &e->st_counts};
     for (DevBuf *b : bufs) b->release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
@@ -538,7 +544,7 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
         ORBGPU_HIP_CHECK(hipStreamWaitEvent(ax, e->ev_fork, 0));
     }
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], ax));
-    if ((rc = launch_blur(ax, nimg, (const uint8_t *)e->pyr.p, (uint8_t *)e->blur.p, G))) return rc;
+    if ((rc = launch_blur(ax, nimg, (const uint8_t *)e->pyr.p, (uint8_t *)e->blur.p, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
     if (!e->serialize) ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
     if ((rc = launch_octree(st, nimg, G, (const uint32_t *)e->slots.p, (const int32_t *)e->cell_counts.p, (uint32_t *)e->cand.p,
