@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
     const uint8_t *L = reinterpret_cast<const uint8_t *>(rs_src);
     uint8_t *D = base + interior_off(gd) + dx0;  // this lane's column in row 0
     const int n = gd.w - dx0;  // columns of this lane inside the level: <= 0 none, 1 the first only
-    int idA = -1, idB = -1, hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0;
+    int hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0;
     YTab ytv[8];  // all eight (uniform) loads in flight at once
 #pragma unroll
     for (int r = 0; r < 8; r++) ytv[r] = yt[min(dy0 + r, gd.h - 1)];
@@ -176,26 +176,23 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
         const int y = dy0 + r;
         if (y >= gd.h) break;
         const YTab yv = ytv[r];
-        if (yv.sy0 == idB) {
-            hA0 = hB0; hA1 = hB1; idA = idB;
-        } else if (yv.sy0 != idA) {
+        // the upper source row is usually the previous output row's lower one (the host marks it): keep its sums
+        if (r > 0 && (yv.pad & 0x10000)) {
+            hA0 = hB0; hA1 = hB1;
+        } else {
             const uint8_t *R = L + (yv.sy0 - sy_min) * P * 4;
             hA0 = (R[xo0] * a00 + R[xr0] * a01) >> 4;
             hA1 = (R[xo1] * a10 + R[xr1] * a11) >> 4;
-            idA = yv.sy0;
         }
-        if (yv.sy1 == idA) {
-            hB0 = hA0; hB1 = hA1; idB = idA;
-        } else if (yv.sy1 != idB) {
+        {
             const uint8_t *R = L + (yv.sy1 - sy_min) * P * 4;
             hB0 = (R[xo0] * a00 + R[xr0] * a01) >> 4;
             hB1 = (R[xo1] * a10 + R[xr1] * a11) >> 4;
-            idB = yv.sy1;
         }
         const int p0 = (((yv.b0 * hA0) >> 16) + ((yv.b1 * hB0) >> 16) + 2) >> 2;
         const int p1 = (((yv.b0 * hA1) >> 16) + ((yv.b1 * hB1) >> 16) + 2) >> 2;
-        // the row and, for rows next to the top / bottom edge, its reflect-101 image in the halo
-        const int ym = (y >= 1 && y <= kEdge) ? -y : ((y >= gd.h - 1 - kEdge && y <= gd.h - 2) ? 2 * (gd.h - 1) - y : y);
+        // the row and, for rows next to the top / bottom edge, its reflect-101 image in the halo (tabulated)
+        const int ym = (yv.pad & 0xFFFF) - 32;
         uint8_t *q = D + y * gd.pitch, *qm = D + ym * gd.pitch;  // 32-bit scalar row offsets (a frame's pyramid is < 2 GiB)
         if (n >= 2) {
             const uint16_t v = (uint16_t)(p0 | (p1 << 8));

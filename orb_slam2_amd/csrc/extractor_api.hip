@@ -217,7 +217,11 @@ static int build_geometry(const orbgpu_extractor *e, int w, int h, Geom *G, std:
                 t.sy1 = sy + 1 < 0 ? 0 : (sy + 1 >= s.h ? s.h - 1 : sy + 1);
                 t.b0 = sat_short((1.f - fy) * 2048);
                 t.b1 = sat_short(fy * 2048);
-                t.pad = 0;
+                // bits 0..15: the row that mirrors dy in the halo rows above / below, plus 32 (dy itself when it has none);
+                // bit 16: the upper source row is the previous output row's lower one (its sums can be kept)
+                const int ym = (dy >= 1 && dy <= kEdge) ? -dy : ((dy >= g.h - 1 - kEdge && dy <= g.h - 2) ? 2 * (g.h - 1) - dy : dy);
+                const bool keep = dy > 0 && yt->back().sy1 == t.sy0;
+                t.pad = (ym + 32) | (keep ? 1 << 16 : 0);
                 yt->push_back(t);
             }
             // source window staged by the largest kRW x kRH output tile (dword-aligned on the left)
