@@ -258,12 +258,13 @@ constexpr int kFastQuad = 4;  // consecutive cells per workgroup in batch launch
 // One FAST cell: geometry of :1043-1072 and where its pixels lie.
 struct FastCell {
     int state;  // 0: past the last cell, 1: skipped by the rules of :1053 / :1068 (count 0), 2: to be searched
-    int l, ci, ci_i, ci_j, cw, ch, ndw, pitch, mdiv, mdivg;
+    int x0, y0, cw, ch, ndw, pitch, mdiv, mdivg, cell_cap;
+    uint32_t slot_off;
     const uint8_t *src;  // the byte left of the cell image's first pixel
 };
 
-// The host tabulates the geometry of every cell (eight words: level | row << 8 | column << 20; state | cw << 8 |
-// ch << 16; iniX | iniY << 16; ceil(2^20 / interior width); ceil(2^20 / pixel groups per row)).
+// The host tabulates every cell in eight words (extractor_api.hip, set_geometry): first interior pixel, state and
+// size, source offset, the two reciprocals, pitch and slot capacity, slot offset.
 __device__ __forceinline__ FastCell fast_cell_info(const uint8_t *__restrict__ pyr, const Geom &G, const uint32_t *__restrict__ cell_tab, int f,
                                                    int cell)
 {
@@ -271,21 +272,20 @@ __device__ __forceinline__ FastCell fast_cell_info(const uint8_t *__restrict__ p
     c.state = 0;
     if (cell >= G.total_cells) return c;
     const uint4 t0 = reinterpret_cast<const uint4 *>(cell_tab)[2 * (size_t)cell];
-    c.l = t0.x & 0xFF; c.ci_i = (t0.x >> 8) & 0xFFF; c.ci_j = t0.x >> 20;
-    const LevelGeom &g = G.lv[c.l];
-    c.ci = cell - g.cell_off;
+    const uint4 t1 = reinterpret_cast<const uint4 *>(cell_tab)[2 * (size_t)cell + 1];
+    c.x0 = t0.x & 0xFFFF; c.y0 = t0.x >> 16;
     c.state = t0.y & 0xFF;
-    if (c.state != 2) return c;
     c.cw = (t0.y >> 8) & 0xFF;
     c.ch = t0.y >> 16;
-    const int iniX = t0.z & 0xFFFF, iniY = t0.z >> 16;
     c.mdiv = (int)t0.w;
-    c.mdivg = (int)cell_tab[8 * (size_t)cell + 4];
+    c.mdivg = (int)t1.x;
+    c.pitch = t1.y & 0xFFFF;
+    c.cell_cap = t1.y >> 16;
+    c.slot_off = t1.z;
     // The cell image goes one byte into the tile rows (tile byte 1 + x of row y = cell image (x, y)): the interior,
     // cell image column 3, then starts on a dword boundary.  The copy reads dwords at byte addresses.
     c.ndw = (c.cw + 4) >> 2;
-    c.pitch = g.pitch;
-    c.src = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)iniY * g.pitch + (iniX - 1);
+    c.src = pyr + (int64_t)f * G.pyr_frame_bytes + t0.z;
     return c;
 }
 
@@ -361,8 +361,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
             if (nx.state == 2) fast_stage_cell(nx, nxt, wave, lane);
             continue;
         }
-        const LevelGeom &g = G.lv[cu.l];
-        const int ci = cu.ci, ci_i = cu.ci_i, ci_j = cu.ci_j;
         const int wi = cu.cw - 6, hi = cu.ch - 6;
     for (int i = tid; i < ((hi + 2) * (kTP / 4) + 3) / 4; i += kFastThreads) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) { qn = 0; nmax = 0; nini = 0; }
@@ -475,7 +473,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     // a maximum in the output is its rank by pixel index among the chosen ones
     const int n = nmax, use_ini = nini > 0;
     const int count = use_ini ? nini : n;
-    uint32_t *slot = slots + (int64_t)f * G.slot_frame_u32 + g.slot_off + (int64_t)ci * g.cell_cap;
+    uint32_t *slot = slots + (int64_t)f * G.slot_frame_u32 + cu.slot_off;
     for (int k = tid; k < n; k += kFastThreads) {
         const uint32_t e = maxima[k];
         if (use_ini && !(e & 0x1000u)) continue;
@@ -487,9 +485,9 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
         }
         const int y = div_small((int)pix, mdiv), x = (int)pix - (int)__umul24(y, wi);
         // keypoint coordinates relative to (16,16): sub-image x (+3 apron) + j*wCell (:1099-1100)
-        if (pos < g.cell_cap) slot[pos] = pack_cand(x + 3 + ci_j * g.wCell, y + 3 + ci_i * g.hCell, (int)(e >> 16));
+        if (pos < cu.cell_cap) slot[pos] = pack_cand(x + cu.x0, y + cu.y0, (int)(e >> 16));
     }
-    if (tid == 0) *cnt_out = min(count, g.cell_cap);
+    if (tid == 0) *cnt_out = min(count, cu.cell_cap);
     fast_stage_wait();  // the next cell's copy: every wave waits for its own pieces, the barrier joins them
     __syncthreads();    // the next cell also reuses the score plane and the counters
     ORB_STAMP(6);

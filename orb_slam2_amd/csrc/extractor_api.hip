@@ -319,18 +319,24 @@ static int set_geometry(orbgpu_extractor *e, int w, int h)
     if ((rc = e->xtab.ensure(xt.size() * sizeof(XTab) + 16))) return rc;
     if ((rc = e->ytab.ensure(yt.size() * sizeof(YTab) + 16))) return rc;
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
-    // FAST cell table, eight words per cell (the geometry of src/ORBextractor.cc:1043-1072, so that the kernel needs
-    // no divisions): level | cell row << 8 | cell column << 20; state | cw << 8 | ch << 16 (state 1: skipped by the
-    // rules of :1053 / :1068, 2: searched; cw x ch = cell image incl. the 3 px apron); iniX | iniY << 16;
-    // ceil(2^20 / interior width); ceil(2^20 / groups of four interior pixels per row); three unused
+    // FAST cell table, eight words per cell (the geometry of src/ORBextractor.cc:1043-1072 and where the cell's data
+    // lie, so that the kernel needs neither divisions nor the level table):
+    //   0: x | y << 16 of the cell's first interior pixel relative to (16,16) (3 + column * wCell, 3 + row * hCell)
+    //   1: state | cw << 8 | ch << 16 (state 1: skipped by the rules of :1053 / :1068, 2: searched; cw x ch = cell
+    //      image incl. the 3 px apron)
+    //   2: byte offset, within a frame's pyramid, of the byte left of the cell image's first pixel
+    //   3: ceil(2^20 / interior width)    4: ceil(2^20 / groups of four interior pixels per row)
+    //   5: row pitch of the level | slot capacity of the cell << 16
+    //   6: offset (in words) of the cell's candidate slot within a frame's slots     7: unused
     std::vector<uint32_t> ctab((size_t)G.total_cells * 8, 0u);
     for (int l = 0; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
         const int maxBX = g.w - kMinBorder, maxBY = g.h - kMinBorder;
         for (int i = 0; i < g.nRows; i++)
             for (int j = 0; j < g.nCols; j++) {
-                uint32_t *r = &ctab[((size_t)g.cell_off + (size_t)i * g.nCols + j) * 8];
-                r[0] = (uint32_t)l | ((uint32_t)i << 8) | ((uint32_t)j << 20);
+                const size_t ci = (size_t)i * g.nCols + j;
+                uint32_t *r = &ctab[((size_t)g.cell_off + ci) * 8];
+                r[0] = (uint32_t)(3 + j * g.wCell) | ((uint32_t)(3 + i * g.hCell) << 16);
                 const int iniY = kMinBorder + i * g.hCell, iniX = kMinBorder + j * g.wCell;
                 int state = 1, cw = 0, ch = 0;
                 if (!(iniY >= maxBY - 3 || iniX >= maxBX - 6)) {
@@ -339,12 +345,14 @@ static int set_geometry(orbgpu_extractor *e, int w, int h)
                     if (cw > 6 && ch > 6) state = 2;
                 }
                 r[1] = (uint32_t)state | ((uint32_t)cw << 8) | ((uint32_t)ch << 16);
-                r[2] = (uint32_t)iniX | ((uint32_t)iniY << 16);
+                r[2] = (uint32_t)(interior_off(g) + (int64_t)iniY * g.pitch + (iniX - 1));
                 if (state == 2) {
                     const int wi = cw - 6, ngx = (wi + 3) >> 2;
                     r[3] = (uint32_t)(((1 << 20) + wi - 1) / wi);
                     r[4] = (uint32_t)(((1 << 20) + ngx - 1) / ngx);
                 }
+                r[5] = (uint32_t)g.pitch | ((uint32_t)g.cell_cap << 16);
+                r[6] = (uint32_t)(g.slot_off + (int64_t)ci * g.cell_cap);
             }
     }
     if ((rc = e->cell_tab.ensure(ctab.size() * 4 + 16))) return rc;
