@@ -484,7 +484,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
             pos += ((o & 0x1000u) >= need && (o & 0xFFFu) < pix) ? 1 : 0;
         }
         const int y = div_small((int)pix, mdiv), x = (int)pix - (int)__umul24(y, wi);
-        // keypoint coordinates relative to (16,16): sub-image x (+3 apron) + j*wCell (:1099-1100)
+        // keypoint coordinates relative to (16,16): position in the cell image + the cell's origin with its
+        // 3 px apron, which the host table holds as (x0, y0) (:1099-1100)
         if (pos < cu.cell_cap) slot[pos] = pack_cand(x + cu.x0, y + cu.y0, (int)(e >> 16));
     }
     if (tid == 0) *cnt_out = min(count, cu.cell_cap);
