@@ -291,3 +291,14 @@ def test_two_handles_from_two_threads(oracle):
         assert np.array_equal(k, refL[0]) and np.array_equal(d, refL[1])
     for k, d in out["R"]:
         assert np.array_equal(k, refR[0]) and np.array_equal(d, refR[1])
+
+
+def test_randomized_sweep(oracle):
+    """A fixed slice of tools/fuzz_parity.py: random sizes, settings and image kinds (noise, checkerboards,
+    saturated blocks, ...) through the extractor, then SearchByProjection and SearchForInitialization of two
+    extractions, all against the oracle."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.main(["--cases", "120", "--seconds", "100", "--seed", "7"]) == 0

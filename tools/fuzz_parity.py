@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Randomized parity sweep of the device path against the CPU oracle (run on the GPU box):
+random image sizes, extractor settings and image kinds through the extractor, then random
+windowed matching of two extractions.  Prints one line per mismatch with the seed that
+reproduces it, and a summary.  usage: python tools/fuzz_parity.py [--seconds 240] [--seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from orb_slam2_amd import api, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402  (the checker)
+
+KINDS = ["scene", "noise", "lownoise", "blocks", "checker", "dots", "saturated", "smooth"]
+
+
+def make_image(kind, w, h, rng):
+    if kind == "scene":
+        return synth.sequence(w, h, 1, seed=int(rng.integers(1 << 30)))[0]
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind == "lownoise":
+        amp = int(rng.integers(4, 40))
+        return (128 + rng.integers(-amp, amp + 1, (h, w))).astype(np.uint8)
+    if kind == "blocks":
+        img = np.full((h, w), int(rng.integers(256)), np.uint8)
+        for _ in range(int(rng.integers(20, 400))):
+            x, y = int(rng.integers(w)), int(rng.integers(h))
+            img[y:y + int(rng.integers(1, 60)), x:x + int(rng.integers(1, 60))] = int(rng.integers(256))
+        return img
+    if kind == "checker":
+        p = int(rng.integers(2, 40))
+        a, b = int(rng.integers(256)), int(rng.integers(256))
+        yy, xx = np.mgrid[0:h, 0:w]
+        return np.where(((yy // p) + (xx // p)) & 1, a, b).astype(np.uint8)
+    if kind == "dots":
+        img = np.full((h, w), int(rng.integers(60, 200)), np.uint8)
+        n = int(rng.integers(1, 3000))
+        img[rng.integers(0, h, n), rng.integers(0, w, n)] = rng.integers(0, 256, n)
+        return img
+    if kind == "saturated":
+        img = np.where(rng.random((h // 8 + 1, w // 8 + 1)) < 0.5, 0, 255).astype(np.uint8)
+        return np.kron(img, np.ones((8, 8), np.uint8))[:h, :w].copy()
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 127 + 100 * np.sin(xx / float(rng.uniform(3, 40))) * np.cos(yy / float(rng.uniform(3, 40)))
+    return (img + rng.integers(-3, 4, (h, w))).clip(0, 255).astype(np.uint8)
+
+
+def compare_extract(ex, oe, img, stats):
+    kps, desc = ex(img)
+    okps, odesc = oe.extract(img)
+    if len(kps) != len(okps):
+        return "keypoint count %d vs oracle %d" % (len(kps), len(okps)), None
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        if not np.array_equal(kps[f], okps[f]):
+            return "field %s differs at %d keypoints" % (f, int((kps[f] != okps[f]).sum())), None
+    if len(kps):
+        dang = np.abs(kps["angle"] - okps["angle"])
+        dang = np.minimum(dang, 360 - dang)
+        stats["angle_max_deg"] = max(stats["angle_max_deg"], float(dang.max()))
+        stats["angle_inexact"] += int((dang != 0).sum())
+        if dang.max() > np.degrees(1e-4):
+            return "angle differs by %g deg" % dang.max(), None
+    nbad = int((desc != odesc).any(axis=1).sum())
+    stats["desc_diff"] += nbad
+    stats["desc_total"] += len(desc)
+    stats["kp_total"] += len(kps)
+    return None, (okps, odesc)
+
+
+def compare_match(m, a, b, w, h, scale, rng):
+    (k1, d1), (k2, d2) = a, b
+    if len(k1) == 0 or len(k2) == 0:
+        return None
+    bounds = np.array([0, 0, w, h], np.float32)
+    mode = int(rng.integers(0, 3))
+    th = float(rng.uniform(2, 60))
+    q = api.shift_queries(k1, float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)), th, scale, bounds)
+    q["flags"] = np.where(rng.random(len(q)) < 0.1, q["flags"] & 1, q["flags"])
+    if mode == 0:
+        q["minLevel"] = k1["octave"] - 1
+        q["maxLevel"] = k1["octave"]
+    occ = (rng.random(len(k2)) < 0.1).astype(np.uint8)
+    q = q.astype(api.WQUERY_DTYPE)
+    ratio = float(rng.uniform(0.5, 1.0))
+    th_dist = int(rng.integers(20, 257))
+    ori = bool(rng.integers(2))
+    m.mfNNratio = ratio
+    m.mbCheckOrientation = ori
+    n, assign = m.SearchByProjection(mode, q, d1, k2, d2, bounds, occupied=occ, th_dist=th_dist)
+    rn, rassign = O.search_by_projection(mode, q.view(O.WQUERY_DTYPE), d1, k2.view(O.KEYPOINT_DTYPE), d2, bounds, occupied=occ,
+                                         th_dist=th_dist, nnratio=ratio, checkOri=ori)
+    if n != rn or not np.array_equal(assign, rassign):
+        return "SearchByProjection mode %d th %.2f ratio %.3f th_dist %d ori %d: %d vs %d matches, %d assignments differ" % (
+            mode, th, ratio, th_dist, ori, n, rn, int((assign != rassign).sum()))
+    win = int(rng.integers(5, 300))
+    mi = api.ORBmatcher(ratio, ori)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32) + rng.uniform(-3, 3, (len(k1), 2)).astype(np.float32)
+    got = mi.SearchForInitialization(k1, d1, k2, d2, bounds, prev, win)
+    ref = O.search_for_initialization(k1.view(O.KEYPOINT_DTYPE), d1, k2.view(O.KEYPOINT_DTYPE), d2, bounds, prev, win, ratio, ori)
+    if got[0] != ref[0] or not np.array_equal(got[1], ref[1]) or not np.array_equal(got[2], ref[2]):
+        return "SearchForInitialization window %d ratio %.3f ori %d: %d vs %d" % (win, ratio, ori, got[0], ref[0])
+    return None
+
+
+def compare_stereo(m, exL, exR, a, b, nlevels, rng):
+    """Frame::ComputeStereoMatches on the two views as a rectified pair (the extractors still hold their pyramids)."""
+    (kL, dL), (kR, dR) = a, b
+    if len(kL) == 0 or len(kR) == 0:
+        return None
+    fx = float(rng.uniform(200, 900))
+    bf = fx * float(rng.uniform(0.05, 0.6))
+    pyrL = [exL.pyramid_level(l) for l in range(nlevels)]
+    pyrR = [exR.pyramid_level(l) for l in range(nlevels)]
+    n, uR, dep = m.ComputeStereoMatches(exL, exR, kL.view(api.KEYPOINT_DTYPE), dL, kR.view(api.KEYPOINT_DTYPE), dR, bf, bf / fx)
+    sc = np.asarray(exL.GetScaleFactors(), np.float32)
+    isc = np.asarray(exL.GetInverseScaleFactors(), np.float32)
+    rn, ruR, rdep = O.stereo_matches(kL.view(O.KEYPOINT_DTYPE), dL, kR.view(O.KEYPOINT_DTYPE), dR, pyrL, pyrR, sc, isc, bf, bf / fx)
+    if n != rn or not np.array_equal(uR, ruR) or not np.array_equal(dep, rdep):
+        return "ComputeStereoMatches bf %.3f fx %.3f: %d vs %d matched, %d uR differ" % (bf, fx, n, rn, int((uR != ruR).sum()))
+    return None
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--case", type=int, default=-1, help="run only this case number")
+    ap.add_argument("--cases", type=int, default=1 << 30, help="stop after this many cases")
+    args = ap.parse_args(argv)
+    O.build()
+    stats = dict(angle_max_deg=0.0, angle_inexact=0, desc_diff=0, desc_total=0, kp_total=0)
+    t_end = time.time() + args.seconds
+    case, nfail, nskip, nmatch = 0, 0, 0, 0
+    m = api.ORBmatcher(0.9, True)
+    while time.time() < t_end and case < args.cases:
+        if args.case >= 0:
+            case = args.case
+        rng = np.random.default_rng([args.seed, case])
+        kind = KINDS[int(rng.integers(len(KINDS)))]
+        scale = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.3, 1.5, 2.0]))
+        nlevels = int(rng.integers(1, 11))
+        w, h = int(rng.integers(70, 1300)), int(rng.integers(70, 1000))
+        if rng.random() < 0.95:
+            h = min(h, 2 * w - 40)  # portrait frames whose search area is more than twice as tall as wide get no quadtree root
+        # the smallest level must keep a search area: sides of at least 62 px
+        while nlevels > 1 and min(w, h) / scale ** (nlevels - 1) < 64:
+            nlevels -= 1
+        nfeat = int(rng.choice([1, 7, 50, 300, 500, 1000, 1000, 2000, 4000, 8000]))
+        ini = int(rng.integers(5, 61))
+        mn = int(rng.integers(1, ini + 1))
+        gauss = int(rng.integers(2))
+        tag = "case %d (seed %d): %s %dx%d nfeat %d scale %.1f levels %d fast %d/%d gauss %d" % (
+            case, args.seed, kind, w, h, nfeat, scale, nlevels, ini, mn, gauss)
+        try:
+            ex = api.ORBextractor(nfeat, scale, nlevels, ini, mn, max_width=w, max_height=h, gauss_variant=gauss)
+        except api.OrbGpuError as e:
+            nskip += 1
+            print("SKIP %s: %s" % (tag, e), flush=True)
+            case += 1
+            if args.case >= 0:
+                break
+            continue
+        ex2 = api.ORBextractor(nfeat, scale, nlevels, ini, mn, max_width=w, max_height=h, gauss_variant=gauss)
+        oe = O.Extractor(nfeat, scale, nlevels, ini, mn, gauss_variant=gauss)
+        img = make_image(kind, w, h, rng)
+        err, a = compare_extract(ex, oe, img, stats)
+        if err is None:
+            l = int(rng.integers(nlevels))
+            if not np.array_equal(ex.pyramid_level(l, border=19), O.border101(oe.level(l), 19)):
+                err = "pyramid level %d (with its border) differs" % l
+            rb = oe.level(l, blurred=True)
+            if err is None and rb is not None and not np.array_equal(ex.pyramid_level(l, blurred=True), rb):
+                err = "blurred level %d differs" % l
+        if err is None:
+            # a second view: the same image shifted by a few pixels with a little noise
+            dx, dy = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+            img2 = np.roll(img, (dy, dx), (0, 1))
+            img2 = (img2.astype(np.int16) + rng.integers(-2, 3, img2.shape)).clip(0, 255).astype(np.uint8)
+            err, b = compare_extract(ex2, oe, img2, stats)
+            if err is None:
+                err = compare_stereo(m, ex, ex2, a, b, nlevels, rng) if rng.random() < 0.5 else None
+            if err is None:
+                err = compare_match(m, a, b, w, h, np.asarray(ex.GetScaleFactors(), np.float32), rng)
+                nmatch += 1
+        if err is not None:
+            nfail += 1
+            print("FAIL %s: %s" % (tag, err), flush=True)
+        elif case % 20 == 0:
+            print("ok   %s (%d keypoints)" % (tag, len(a[0])), flush=True)
+        case += 1
+        if args.case >= 0:
+            break
+    print("cases %d, failed %d, skipped %d, matched pairs %d; keypoints %d, angles not bit-identical %d (max %.3g deg), "
+          "descriptors differing %d of %d" % (case, nfail, nskip, nmatch, stats["kp_total"], stats["angle_inexact"],
+                                             stats["angle_max_deg"], stats["desc_diff"], stats["desc_total"]), flush=True)
+    return 1 if nfail else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
