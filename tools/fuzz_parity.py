@@ -108,6 +108,99 @@ def compare_match(m, a, b, w, h, scale, rng):
     return None
 
 
+def _featvec(desc, nbits):
+    """Stand-in FeatureVector: node id = leading descriptor bits."""
+    node = desc[:, 0].astype(np.int32) >> (8 - nbits)
+    return {int(n): np.nonzero(node == n)[0].tolist() for n in np.unique(node)}
+
+
+def compare_match2(a, b, w, h, scale, rng):
+    """SearchByBoW, SearchForTriangulation and the area search of Fuse / SearchBySim3 with random settings."""
+    (k1, d1), (k2, d2) = a, b
+    if len(k1) == 0 or len(k2) == 0:
+        return None
+    bounds = np.array([0, 0, w, h], np.float32)
+    ratio, ori = float(rng.uniform(0.5, 1.0)), bool(rng.integers(2))
+    m = api.ORBmatcher(ratio, ori)
+    nbits = int(rng.integers(0, 7))
+    fv1, fv2 = _featvec(d1, nbits), _featvec(d2, nbits)
+    if len(fv1) > 3 and len(fv2) > 3:
+        fv1.pop(sorted(fv1)[1]); fv2.pop(sorted(fv2)[-2])
+    strict = bool(rng.integers(2))
+    valid1 = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+    excl2 = (rng.random(len(k2)) < 0.1).astype(np.uint8) if strict else None
+    n, a1, m12 = m.SearchByBoW(fv1, k1, d1, valid1, fv2, k2, d2, excl2, strict)
+    qi, qs, ss, si = api.bow_segments(fv1, fv2, valid1)
+    q = np.zeros(len(qi), O.WQUERY_DTYPE)
+    q["angle"] = k1["angle"][qi]; q["minLevel"] = qs; q["flags"] = 1
+    rn, rassign, rqm = O.search_by_bow(q, d1[qi], k2.view(O.KEYPOINT_DTYPE), d2, ss, si, excl2, 49 if strict else 50, ratio, ori)
+    ra1 = np.where(rassign >= 0, qi[np.clip(rassign, 0, None)], -1) if len(qi) else np.full(len(k2), -1, np.int32)
+    rm12 = np.full(len(k1), -1, np.int32); rm12[qi[rqm >= 0]] = rqm[rqm >= 0]
+    if n != rn or not np.array_equal(a1, ra1) or not np.array_equal(m12, rm12):
+        return "SearchByBoW nbits %d ratio %.3f ori %d strict %d: %d vs %d" % (nbits, ratio, ori, strict, n, rn)
+
+    stereo, only_stereo = bool(rng.integers(2)), bool(rng.integers(2))
+    has1 = rng.random(len(k1)) < 0.2; has2 = rng.random(len(k2)) < 0.2
+    ur1 = np.where(rng.random(len(k1)) < 0.6, k1["x"] - 7.0, -1.0).astype(np.float32) if stereo else None
+    ur2 = np.where(rng.random(len(k2)) < 0.6, k2["x"] - 7.0, -1.0).astype(np.float32) if stereo else None
+    ang = float(rng.uniform(0, 2 * np.pi))
+    t = np.array([np.cos(ang), np.sin(ang)], np.float32)
+    F12 = np.array([[0, 0, t[1]], [0, 0, -t[0]], [-t[1], t[0], 0]], np.float32)
+    epipole = (float(rng.uniform(0, w)), float(rng.uniform(0, h)))
+    scale2 = np.asarray(scale, np.float32); sigma2 = (scale2 * scale2).astype(np.float32)
+    n, m12 = m.SearchForTriangulation(fv1, k1, d1, has1, ur1, fv2, k2, d2, has2, ur2, F12, epipole, scale2, sigma2, only_stereo)
+    stereo1 = np.zeros(len(k1), bool) if ur1 is None else ur1 >= 0
+    use1 = ~has1 & (stereo1 if only_stereo else True)
+    qi, qs, ss, si = api.bow_segments(fv1, fv2, use1)
+    q = np.zeros(len(qi), O.WQUERY_DTYPE)
+    q["u"] = k1["x"][qi]; q["v"] = k1["y"][qi]; q["angle"] = k1["angle"][qi]; q["minLevel"] = qs; q["flags"] = 1 + 4 * stereo1[qi]
+    rn, rqm = O.search_for_triangulation(q, d1[qi], k2.view(O.KEYPOINT_DTYPE), d2, ur2, ss, si, has2.astype(np.uint8), F12,
+                                         epipole[0], epipole[1], scale2, sigma2, only_stereo, ori)
+    rm12 = np.full(len(k1), -1, np.int32); rm12[qi[rqm >= 0]] = rqm[rqm >= 0]
+    if n != rn or not np.array_equal(m12, rm12):
+        return "SearchForTriangulation nbits %d stereo %d/%d ori %d: %d vs %d" % (nbits, stereo, only_stereo, ori, n, rn)
+
+    th, chi2, th_dist = float(rng.uniform(1, 40)), bool(rng.integers(2)), int(rng.integers(20, 257))
+    q = api.shift_queries(k1, float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)), th, scale2, bounds)
+    q["minLevel"] = k1["octave"] - 1; q["maxLevel"] = k1["octave"]
+    q["u"] += rng.normal(0, 1.0, len(q)).astype(np.float32); q["v"] += rng.normal(0, 1.0, len(q)).astype(np.float32)
+    q["ur"] = q["u"] - 6.0
+    q["flags"] = np.where(rng.random(len(q)) < 0.1, 0, 3)
+    q = q.astype(api.WQUERY_DTYPE)
+    inv_s2 = (1.0 / sigma2).astype(np.float32)
+    n, qm = m.SearchInArea(q, d1, k2, d2, bounds, ur2, inv_s2, chi2, th_dist)
+    rn, rqm = O.search_in_area(q.view(O.WQUERY_DTYPE), d1, k2.view(O.KEYPOINT_DTYPE), d2, bounds, ur2, inv_s2, chi2, th_dist)
+    if n != rn or not np.array_equal(qm, rqm):
+        return "SearchInArea th %.2f chi2 %d th_dist %d: %d vs %d" % (th, chi2, th_dist, n, rn)
+    return None
+
+
+def compare_bow(a, rng):
+    """The vocabulary transform of one view's descriptors against a random vocabulary."""
+    d = a[1]
+    k, L = int(rng.integers(2, 21)), int(rng.integers(1, 5))
+    if k ** L > 20000:
+        L = 2
+    weighting, scoring = int(rng.integers(4)), int(rng.integers(6))
+    voc = synth.vocabulary(k, L, seed=int(rng.integers(1 << 30)), ragged=bool(rng.integers(2)), scoring=scoring, weighting=weighting)
+    # half of the vocabulary's words are descriptors of the view, so that the descent is not decided at the root
+    leaves = np.nonzero(voc["is_leaf"] == 1)[0]
+    if len(d):
+        take = leaves[rng.random(len(leaves)) < 0.5]
+        voc["desc"][take] = d[rng.integers(0, len(d), len(take))]
+    v = api.ORBVocabulary.from_arrays(voc["k"], voc["L"], voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"],
+                                      scoring=scoring, weighting=weighting)
+    levelsup = int(rng.integers(0, L + 2))
+    got = v.transform_arrays(d, levelsup)
+    ref = O.voc_transform(voc, d, levelsup)
+    ok = (np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2][0], ref[2][0])
+          and np.array_equal(got[2][1].view(np.uint64), ref[2][1].view(np.uint64))
+          and all(np.array_equal(x, y) for x, y in zip(got[3], ref[3])))
+    if not ok:
+        return "vocabulary transform k %d L %d weighting %d scoring %d levelsup %d differs" % (k, L, weighting, scoring, levelsup)
+    return None
+
+
 def compare_stereo(m, exL, exR, a, b, nlevels, rng):
     """Frame::ComputeStereoMatches on the two views as a rectified pair (the extractors still hold their pyramids)."""
     (kL, dL), (kR, dR) = a, b
@@ -187,7 +280,11 @@ def main(argv=None):
                 err = compare_stereo(m, ex, ex2, a, b, nlevels, rng) if rng.random() < 0.5 else None
             if err is None:
                 err = compare_match(m, a, b, w, h, np.asarray(ex.GetScaleFactors(), np.float32), rng)
-                nmatch += 1
+            if err is None and rng.random() < 0.5:
+                err = compare_match2(a, b, w, h, np.asarray(ex.GetScaleFactors(), np.float32), rng)
+            if err is None and rng.random() < 0.3 and len(a[0]) <= 16384:
+                err = compare_bow(a, rng)
+            nmatch += 1
         if err is not None:
             nfail += 1
             print("FAIL %s: %s" % (tag, err), flush=True)
