@@ -195,6 +195,27 @@ def test_batch_of_ten_and_profiling_modes(oracle):
     ex.profile(0)
 
 
+def test_batch_of_64_dense_frames(oracle):
+    """The launch shapes of large batches (four FAST cells per workgroup, the batched quadtree kernel, frames pinned
+    to XCDs) on frames that fill the feature budget: every frame equals its single-frame extraction, and a sample
+    equals the oracle."""
+    seq = synth.sequence(640, 480, 64, seed=5, per_frame_density=True)
+    ex = _mk(640, 480, 1000, max_batch=64)
+    res = ex.extract_batch(seq)
+    one = _mk(640, 480, 1000)
+    oe = oracle.Extractor(1000)
+    assert min(len(r[0]) for r in res) > 900
+    for i in range(64):
+        k1, d1 = one(seq[i])
+        assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1), "frame %d" % i
+    for i in (0, 31, 63):
+        okps, odesc = oe.extract(seq[i])
+        assert len(okps) == len(res[i][0])
+        for f in ("x", "y", "size", "response", "octave", "class_id"):
+            assert np.array_equal(res[i][0][f], okps[f]), f
+        assert int((res[i][1] != odesc).any(axis=1).sum()) <= 0.001 * len(odesc)
+
+
 def test_degenerate_images(oracle):
     ex = _mk(640, 480, 1000)
     k, d = ex(np.zeros((0, 0), np.uint8))
