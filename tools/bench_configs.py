@@ -112,8 +112,9 @@ if __name__ == "__main__":
         stereo("KITTI 1241x376 stereo, 2000 features/side + ComputeStereoMatches", 1241, 376, 2000, 386.1448, 718.856, 2)
     if "euroc" in which:
         stereo("EuRoC 752x480 stereo, 1200 features/side + ComputeStereoMatches", 752, 480, 1200, 47.90639384423901, 435.2046959714599, 3)
-    if "4k" in which:
-        batch_4k()
+    for a in which:
+        if a.startswith("4k"):  # "4k" or "4k:256" (frames per launch)
+            batch_4k(int(a.split(":")[1]) if ":" in a else 16)
     if "bf" in which:
         brute()
     if "bow" in which:

@@ -1,6 +1,6 @@
 """Debug aid: mean cycle-counter ticks per phase of k_fast_cells, per cell.
-Needs a library built with the phase stamps: make -C orb_slam2_amd/csrc CXXFLAGS+=-DORBGPU_STAMPS (and a plain
-rebuild afterwards: the stamped kernel is slower).  Run on the GPU box: python tools/fast_stamps.py"""
+Needs a library built with the phase stamps: touch the .hip files, then make -C orb_slam2_amd/csrc with the
+Makefile's CXXFLAGS plus -DORBGPU_STAMPS (and a plain rebuild afterwards: the stamped kernel is slower).  Run on the GPU box: python tools/fast_stamps.py"""
 import sys, ctypes as C, numpy as np
 sys.path.insert(0, '.')
 import torch
