@@ -130,10 +130,10 @@ int orbgpu_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, int3
                          int32_t border, uint8_t *dst, int32_t dst_stride, int32_t *w,
                          int32_t *h);
 /* Device view of the same plane (interior pointer + pitch); valid until the
- * next extract call on the handle.  Around the interior the plane carries the
- * 19 halo rows and 4 halo columns per side (what the extraction reads); the
- * other 15 halo columns are filled by the first orbgpu_pyramid_level call with
- * border > 4 after an extraction. */
+ * next extract call on the handle.  Above and below the interior the plane
+ * carries the 19 halo rows; the 19 halo columns per side, which the extraction
+ * never reads, are filled by the first orbgpu_pyramid_level call with
+ * border > 0 after an extraction. */
 int orbgpu_pyramid_level_device(orbgpu_extractor *e, int32_t frame, int32_t level,
                                 int32_t blurred, const uint8_t **d_ptr, int32_t *pitch,
                                 int32_t *w, int32_t *h);

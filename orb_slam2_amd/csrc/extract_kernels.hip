@@ -30,7 +30,7 @@ __device__ __forceinline__ void store_row_span(uint8_t *row, int x0, int n, cons
 
 // A span of a level plus its reflect-101 image in the halo rows above/below
 // (copyMakeBorder BORDER_REFLECT_101, src/ORBextractor.cc:1567-1586); the halo
-// columns are filled by k_halo4 / k_halo_sides.  Needs h >= 2*kEdge+2.
+// columns are filled by k_halo_sides when a caller asks for them.  Needs h >= 2*kEdge+2.
 template <int NW>
 __device__ __forceinline__ void store_span_with_halo(uint8_t *in, int pitch, int w, int h, int x0, int y, int n,
                                                      const uint32_t (&v)[NW])
@@ -41,7 +41,8 @@ __device__ __forceinline__ void store_span_with_halo(uint8_t *in, int pitch, int
 }
 
 // Left/right halo columns of every level and every row (halo rows included),
-// one thread per pixel, all levels in one launch.
+// one thread per pixel, all levels in one launch.  The extraction itself reads no halo column (the blur forms
+// the three reflected columns it needs in registers): this runs when a caller asks for a level with its border.
 __global__ __launch_bounds__(256) void k_halo_sides(uint8_t *__restrict__ pyr, Geom G)
 {
     int f, b;  // a workgroup = 16 rows (38 columns padded to 64 lanes) of one level
@@ -65,34 +66,6 @@ __global__ __launch_bounds__(256) void k_halo_sides(uint8_t *__restrict__ pyr, G
 #pragma unroll
     for (int r = 0; r < 4; r++)
         if (y0 + r < g.h + kEdge) row[(int64_t)r * g.pitch + x] = v[r];
-}
-
-// The four halo columns next to the interior on each side, every level and every row (halo rows included): all
-// that the extraction itself reads beyond the interior (the blur reaches 3 px).  A thread mirrors one side of one
-// row: columns -4..-1 = columns 4..1, columns w..w+3 = columns w-2..w-5.  k_halo_sides completes the 19 columns
-// when a caller asks for a level with its border.
-__global__ __launch_bounds__(64) void k_halo4(uint8_t *__restrict__ pyr, Geom G)
-{
-    const int f = blockIdx.y;
-    int b = blockIdx.x, l = 0;  // a workgroup = 32 rows x 2 sides of one level
-    while (true) {
-        const int n = (G.lv[l].h + 2 * kEdge + 31) >> 5;
-        if (b < n) break;
-        b -= n;
-        if (++l >= G.nlevels) return;
-    }
-    const LevelGeom &g = G.lv[l];
-    const int y = b * 32 + (threadIdx.x >> 1) - kEdge;
-    if (y >= g.h + kEdge) return;
-    uint8_t *row = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g) + (int64_t)y * g.pitch;
-    if (threadIdx.x & 1) {
-        // byte addresses: w is arbitrary
-        const uint32_t s = *reinterpret_cast<const uint32_t *>(row + g.w - 5);
-        *reinterpret_cast<uint32_t *>(row + g.w) = __builtin_amdgcn_perm(0u, s, 0x00010203u);
-    } else {
-        const uint2 s = *reinterpret_cast<const uint2 *>(row);  // rows are 32-byte aligned
-        *reinterpret_cast<uint32_t *>(row - 4) = __builtin_amdgcn_perm(s.y, s.x, 0x01020304u);
-    }
 }
 
 // Level 0 = the input image; 16 pixels per thread, 128-bit accesses when the
@@ -977,9 +950,9 @@ __global__ __launch_bounds__(256, 8) void k_octree_batch(OCTREE_ARGS)
 
 // ---------------------------------------------------------------------------
 // GaussianBlur 7x7, sigma 2, 8-bit fixed point (called at :1502).  All levels
-// in one launch; the 19 px halo of the source supplies the reflect-101 border.
-// Tile = 128 x 32 pixels per 256-thread workgroup; every thread moves and
-// computes four horizontally adjacent pixels (32-bit global accesses, 64-bit
+// in one launch; the halo rows of the source supply the reflect-101 border above and below.
+// Tile = 64 x 32 pixels per one-wave workgroup; every thread moves and
+// computes four horizontally adjacent pixels (32-bit global accesses, 128-bit
 // LDS accesses for the 16-bit row sums).
 // ---------------------------------------------------------------------------
 constexpr int kBW = 64, kBH = 32;        // output tile of one blur workgroup
@@ -1003,6 +976,63 @@ __device__ __forceinline__ void blur_row4(uint32_t a, uint32_t b, uint32_t d, ui
 
 __device__ __forceinline__ uint32_t u4_at(const uint4 &v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
 
+// Horizontal pass of one tile straight from global memory (rows ty0-3 .. ty0+kBH+2, clamped into the halo): a
+// thread takes two source rows x four columns (three aligned dwords per row: neighbours' loads overlap in L1) and
+// writes four packed dwords.  EDGE: the tile touches the left or the right edge of the level.
+template <bool EDGE>
+__device__ __forceinline__ void blur_rows(const uint8_t *__restrict__ in, const LevelGeom &g, int tx0, int ty0, uint32_t klo,
+                                          uint32_t khi, uint32_t *hpair)
+{
+    const int tid = threadIdx.x;
+    const int xlim = (g.w + 15) & ~3, ylim = g.h + 2;
+    constexpr int CG = kBW / 4;  // column groups of a tile row
+    const bool left_edge = tx0 == 0, right_edge = g.w < tx0 + kBW + 4;  // uniform
+    for (int i = tid; i < (kBH + 6) / 2 * CG; i += kBlurThreads) {
+        const int rp = i / CG, c = i % CG;
+        const int y0 = min(ty0 + 2 * rp - 3, ylim), y1 = min(ty0 + 2 * rp - 2, ylim);
+        const int xa = min(tx0 - 4 + 4 * c, xlim), xb = min(tx0 + 4 * c, xlim), xd = min(tx0 + 4 + 4 * c, xlim);
+        const uint8_t *r0 = in + (int64_t)y0 * g.pitch, *r1 = in + (int64_t)y1 * g.pitch;
+        // right edge: columns w .. w+3 = columns w-2, w-3, w-4, w-5; w is arbitrary, so these come out of the two
+        // aligned dwords that hold them, loaded by every lane of an edge tile together with the tile's own dwords.
+        const int hx = (g.w - 5) & ~3, hs = (g.w - 5) & 3;
+        uint32_t hl0 = 0, hh0 = 0, hl1 = 0, hh1 = 0;
+        if (EDGE && right_edge) {
+            hl0 = *reinterpret_cast<const uint32_t *>(r0 + hx); hh0 = *reinterpret_cast<const uint32_t *>(r0 + hx + 4);
+            hl1 = *reinterpret_cast<const uint32_t *>(r1 + hx); hh1 = *reinterpret_cast<const uint32_t *>(r1 + hx + 4);
+        }
+        uint32_t a0 = *reinterpret_cast<const uint32_t *>(r0 + xa), b0 = *reinterpret_cast<const uint32_t *>(r0 + xb),
+                 d0 = *reinterpret_cast<const uint32_t *>(r0 + xd);
+        uint32_t a1 = *reinterpret_cast<const uint32_t *>(r1 + xa), b1 = *reinterpret_cast<const uint32_t *>(r1 + xb),
+                 d1 = *reinterpret_cast<const uint32_t *>(r1 + xd);
+        if (EDGE && left_edge && c == 0) {  // columns -4 .. -1 = columns 4, 3, 2, 1
+            a0 = __builtin_amdgcn_perm(d0, b0, 0x01020304u);
+            a1 = __builtin_amdgcn_perm(d1, b1, 0x01020304u);
+        }
+        if (EDGE && right_edge) {
+            const uint32_t h0 = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(hh0, hl0, hs), 0x00010203u);
+            const uint32_t h1 = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(hh1, hl1, hs), 0x00010203u);
+            int tr = g.w - xb;  // interior columns from this group's first one to the edge
+            asm("" : "+v"(tr));  // opaque: the conditions below do not change along the loop, and a branch on them
+                                 // would put the loads of h behind a second wait
+            const int n = 4 - (tr & 3), sh = (8 * n) & 31;
+            const bool in_b = tr >= 1 && tr <= 3;  // the edge lies in the middle dword: its first tr bytes stay
+            const bool in_d = tr >= 5 && tr <= 7;  // the edge lies in the third dword: its first tr-4 bytes stay
+            const uint32_t mb0 = __builtin_amdgcn_alignbyte(h0, b0 << sh, n), mb1 = __builtin_amdgcn_alignbyte(h1, b1 << sh, n);
+            const uint32_t md0 = __builtin_amdgcn_alignbyte(h0, d0 << sh, n), md1 = __builtin_amdgcn_alignbyte(h1, d1 << sh, n);
+            // the third dword: continues the reflection behind a patched middle dword, is the reflection (tr = 4),
+            // or keeps its first bytes
+            d0 = in_b ? h0 >> sh : tr == 4 ? h0 : in_d ? md0 : d0;
+            d1 = in_b ? h1 >> sh : tr == 4 ? h1 : in_d ? md1 : d1;
+            b0 = in_b ? mb0 : b0;
+            b1 = in_b ? mb1 : b1;
+        }
+        uint32_t e[4], o[4];
+        blur_row4(a0, b0, d0, klo, khi, e);
+        blur_row4(a1, b1, d1, klo, khi, o);
+        *reinterpret_cast<uint4 *>(hpair + rp * kBW + 4 * c) = make_uint4(e[0] | (o[0] << 16), e[1] | (o[1] << 16), e[2] | (o[2] << 16), e[3] | (o[3] << 16));
+    }
+}
+
 // One wave per 64 x 32 tile: narrow tiles waste few lanes on the level widths, and the 19 x 16 horizontal tasks
 // fill five passes of the wave almost completely.
 __global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G,
@@ -1021,26 +1051,15 @@ __global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict
     const uint32_t k0 = 18, k1 = 34, k2 = G.gauss_variant ? 48 : 49, k3 = G.gauss_variant ? 56 : 55;
     const uint32_t klo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), khi = k2 | (k1 << 8) | (k0 << 16);
     const uint8_t *in = pyr + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
-    // horizontal pass straight from global memory (rows ty0-3 .. ty0+kBH+2, clamped into the halo):
-    // a thread takes two source rows x four columns (three aligned dwords per row: neighbours'
-    // loads overlap in L1) and writes four packed dwords
-    const int xlim = (g.w + 15) & ~3, ylim = g.h + 2;
-    constexpr int CG = kBW / 4;  // column groups of a tile row
-    for (int i = tid; i < (kBH + 6) / 2 * CG; i += kBlurThreads) {
-        const int rp = i / CG, c = i % CG;
-        const int y0 = min(ty0 + 2 * rp - 3, ylim), y1 = min(ty0 + 2 * rp - 2, ylim);
-        const int xa = min(tx0 - 4 + 4 * c, xlim), xb = min(tx0 + 4 * c, xlim), xd = min(tx0 + 4 + 4 * c, xlim);
-        const uint8_t *r0 = in + (int64_t)y0 * g.pitch, *r1 = in + (int64_t)y1 * g.pitch;
-        uint32_t e[4], o[4];
-        blur_row4(*reinterpret_cast<const uint32_t *>(r0 + xa), *reinterpret_cast<const uint32_t *>(r0 + xb),
-                  *reinterpret_cast<const uint32_t *>(r0 + xd), klo, khi, e);
-        blur_row4(*reinterpret_cast<const uint32_t *>(r1 + xa), *reinterpret_cast<const uint32_t *>(r1 + xb),
-                  *reinterpret_cast<const uint32_t *>(r1 + xd), klo, khi, o);
-        *reinterpret_cast<uint4 *>(hpair + rp * kBW + 4 * c) = make_uint4(e[0] | (o[0] << 16), e[1] | (o[1] << 16), e[2] | (o[2] << 16), e[3] | (o[3] << 16));
-    }
+    // The halo rows hold the reflect-101 image of the interior (the producers write them); the three reflected
+    // columns on either side are formed here from the row's own interior, in the tiles that touch an edge (their
+    // own copy of the loop: the other tiles run without the checks).
+    if (tx0 == 0 || g.w < tx0 + kBW + 4) blur_rows<true>(in, g, tx0, ty0, klo, khi, hpair);
+    else blur_rows<false>(in, g, tx0, ty0, klo, khi, hpair);
     __syncthreads();
     // vertical pass: thread = 4 columns x 8 rows; output row y0+rr sums source rows y0+rr .. y0+rr+6,
     // i.e. four row pairs with the taps aligned for an even or an odd first row
+    constexpr int CG = kBW / 4;  // column groups of a tile row
     const int c = tid % CG, rg = tid / CG;
     const int x = tx0 + 4 * c;
     uint8_t *out = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
@@ -1352,19 +1371,16 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     G.nimg = nimg;
     const LevelGeom &g0 = G.lv[0];
     hipLaunchKernelGGL(k_pyr_copy0, dim3((((g0.w + 15) / 16) * g0.h + 255) / 256, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G_);
-    int rows = (g0.h + 2 * kEdge + 31) / 32;
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
-        rows += (g.h + 2 * kEdge + 31) / 32;
         hipLaunchKernelGGL(k_pyr_resize, dim3(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), grid_frames(nimg)), dim3(256),
                            (size_t)g.rs_rows * g.rs_pitch_dw * 4, st, pyr, G, l, xtab, ytab);
     }
-    hipLaunchKernelGGL(k_halo4, dim3(rows, nimg), dim3(64), 0, st, pyr, G_);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
 
-// All 19 halo columns of every level (the extraction fills only the 4 it reads).
+// All 19 halo columns of every level (the extraction writes none).
 int launch_halo_full(hipStream_t st, int nimg, uint8_t *pyr, const Geom &G)
 {
     int rows = 0;

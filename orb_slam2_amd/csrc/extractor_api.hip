@@ -81,7 +81,7 @@ struct orbgpu_extractor {
     Geom G;
     int geom_w = 0, geom_h = 0;
     int last_nimg = 0;
-    bool halo_full = false;  // the last extraction's levels carry all 19 halo columns (filled on demand)
+    bool halo_full = false;  // the last extraction's levels carry their halo columns (filled on demand)
     DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab, cell_tab, blur_tab;
     int blur_tiles = 0;
     DevBuf st_img, st_kps, st_desc, st_counts;  // staging for the host entry points
@@ -678,8 +678,8 @@ int orbgpu_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, int3
     if (!dst) return ORBGPU_OK;
     if (dst_stride < lw + 2 * border) return ORBGPU_E_INVALID;
     ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
-    if (border > 4 && !e->halo_full) {
-        // the extraction fills the halo rows and the 4 halo columns it reads itself; the other 15 on first request
+    if (border > 0 && !e->halo_full) {
+        // the extraction fills the halo rows only (it reads no halo column); the columns on first request
         if ((rc = launch_halo_full(e->stream, e->last_nimg, (uint8_t *)e->pyr.p, e->G))) return rc;
         e->halo_full = true;
     }

@@ -273,8 +273,9 @@ def test_4k_frame_8000_features(oracle):
 
 
 def test_halo_columns_are_completed_on_request(oracle):
-    """The extraction writes the 19 halo rows and 4 halo columns per side; the other 15 columns are filled when a
-    level is first asked for with its border -- for the images of the latest extraction, not an earlier one."""
+    """The extraction writes the 19 halo rows and no halo column (the blur forms the reflected columns it reads
+    itself); the columns are filled when a level is first asked for with its border -- for the images of the latest
+    extraction, not an earlier one."""
     seq = synth.sequence(640, 480, 3, seed=17)
     ex = _mk(640, 480, 1000, max_batch=2)
     oe = oracle.Extractor(1000)
