@@ -21,6 +21,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this driver needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle errors otherwise)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 640, 480, 1000, 8, 1.2, 20, 7
 STEP = (2, 1)   # per-frame image motion of the synthetic sequence
