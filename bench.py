@@ -80,9 +80,17 @@ def main():
 
     from orb_slam2_amd.dist import env_world, max_over_ranks
     rank, local_rank, world = env_world()
+    # rehearsal of the multi-rank path on a one-GPU box: ORBGPU_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # lines the ranks up over gloo (RCCL refuses two ranks on one device); never set in a measured run
+    rehearsal = os.environ.get("ORBGPU_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -180,7 +188,7 @@ def main():
     iso_ms, _ = ex.stage_times()
     ex.profile(False)
 
-    wall_max = max_over_ranks(wall, dev)
+    wall_max = max_over_ranks(wall, None if rehearsal else dev)
 
     wstats = [mt.window_stats(p) for p in range(0, Bs, max(1, Bs // 8))]
     kp_mean = float(d_cnt[1:].float().mean().item())
@@ -267,7 +275,7 @@ def main():
             "config": {"workload": "TUM mono 640x480, 1000 features, 8 levels, scale 1.2, FAST 20/7: extract + "
                                    "SearchByProjection(Cur,Last) th=15 against the previous frame",
                        "batch_per_gpu": B, "streams": S, "keypoints_per_frame": kp_mean, "matches_per_frame": nm_mean,
-                       "parallelism": "frames sharded across %d GPU(s), no collective" % world},
+                       "parallelism": "frames sharded across %d GPU(s), no collective" % world + (" (REHEARSAL: all ranks on one device)" if rehearsal else "")},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": float(stage_ms[dom]),
