@@ -82,6 +82,13 @@ struct orbgpu_extractor {
     int geom_w = 0, geom_h = 0;
     int last_nimg = 0;
     bool halo_full = false;  // the last extraction's levels carry their halo columns (filled on demand)
+    // the host-pointer entry point replays its launches (upload, eleven kernels on two streams, downloads) as one
+    // HIP graph, captured the first time a (frames, width, height) combination is seen: a single frame is bound by
+    // launch overhead, not by the kernels
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_nimg = 0, graph_w = 0, graph_h = 0;
+    bool graph_broken = false;  // capture failed once: plain launches from then on
     DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab, cell_tab, blur_tab;
     int blur_tiles = 0;
     DevBuf st_img, st_kps, st_desc, st_counts;  // staging for the host entry points
@@ -303,9 +310,12 @@ static int ensure_buffers(orbgpu_extractor *e, const Geom &G, int batch, int img
 }
 
 // Select the geometry for w x h (recomputing tables when the size changes).
+static void drop_graph(orbgpu_extractor *e);
+
 static int set_geometry(orbgpu_extractor *e, int w, int h)
 {
     if (w == e->geom_w && h == e->geom_h) return ORBGPU_OK;
+    drop_graph(e);  // the captured launches name the old geometry's tables and buffers
     if (w > e->p.max_width || h > e->p.max_height) {
         set_error("image %dx%d exceeds the handle's max %dx%d", w, h, e->p.max_width, e->p.max_height);
         return ORBGPU_E_INVALID;
@@ -431,6 +441,7 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e)
     if (!e) return;
     (void)hipSetDevice(e->p.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    drop_graph(e);
     DevBuf *bufs[] = {&e->pyr, &e->blur, &e->slots, &e->cell_counts, &e->cand, &e->nodes, &e->scratch, &e->sel, &e->sel_count,
                       &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->cell_tab, &e->blur_tab, &e->st_img, &e->st_kps, &e->st_desc, &e->st_counts};
     for (DevBuf *b : bufs) b->release();
@@ -514,6 +525,17 @@ int orbgpu_extractor_max_keypoints(const orbgpu_extractor *e, int32_t *max_kp)
     if (!e || !max_kp) return ORBGPU_E_INVALID;
     *max_kp = e->G.total_kp_cap;
     return ORBGPU_OK;
+}
+
+static constexpr int kGraphMaxFrames = 8;  // beyond a few frames the kernels dominate and plain launches do as well
+
+static void drop_graph(orbgpu_extractor *e)
+{
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    e->graph_exec = nullptr;
+    e->graph = nullptr;
+    e->graph_nimg = 0;
 }
 
 int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int32_t nimg, int32_t w, int32_t h,
@@ -600,19 +622,55 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
         uint8_t *hin = h_in + (size_t)f * w * h;
         for (int y = 0; y < h; y++) memcpy(hin + (size_t)y * w, imgs[f] + (size_t)y * stride, (size_t)w);
     }
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(e->st_img.p, h_in, (size_t)nimg * w * h, hipMemcpyHostToDevice, st));
-    rc = orbgpu_extract_batch_device(e, (const uint8_t *)e->st_img.p, nimg, w, h, w, (size_t)w * h,
-                                     (orbgpu_keypoint *)e->st_kps.p, (uint8_t *)e->st_desc.p, cap, (int32_t *)e->st_counts.p);
-    if (rc) return rc;
     uint8_t *hp = (uint8_t *)e->h_pinned;
     orbgpu_keypoint *h_kps = (orbgpu_keypoint *)hp;
     uint8_t *h_desc = hp + (size_t)nimg * cap * sizeof(orbgpu_keypoint);
     int32_t *h_counts = (int32_t *)(h_desc + (size_t)nimg * cap * 32);
     int32_t *h_status = h_counts + nimg;
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(h_kps, e->st_kps.p, (size_t)nimg * cap * sizeof(orbgpu_keypoint), hipMemcpyDeviceToHost, st));
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(h_desc, e->st_desc.p, (size_t)nimg * cap * 32, hipMemcpyDeviceToHost, st));
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(h_counts, e->st_counts.p, (size_t)nimg * 4, hipMemcpyDeviceToHost, st));
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(h_status, e->status.p, 4, hipMemcpyDeviceToHost, st));
+    // upload, extraction, downloads: every address involved belongs to the handle, so the sequence is the same for
+    // every call with this geometry and batch size
+    auto enqueue = [&]() -> int {
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(e->st_img.p, h_in, (size_t)nimg * w * h, hipMemcpyHostToDevice, st));
+        int r = orbgpu_extract_batch_device(e, (const uint8_t *)e->st_img.p, nimg, w, h, w, (size_t)w * h,
+                                            (orbgpu_keypoint *)e->st_kps.p, (uint8_t *)e->st_desc.p, cap, (int32_t *)e->st_counts.p);
+        if (r) return r;
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(h_kps, e->st_kps.p, (size_t)nimg * cap * sizeof(orbgpu_keypoint), hipMemcpyDeviceToHost, st));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(h_desc, e->st_desc.p, (size_t)nimg * cap * 32, hipMemcpyDeviceToHost, st));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(h_counts, e->st_counts.p, (size_t)nimg * 4, hipMemcpyDeviceToHost, st));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(h_status, e->status.p, 4, hipMemcpyDeviceToHost, st));
+        return ORBGPU_OK;
+    };
+    const bool want_graph = !e->profile && !e->graph_broken && nimg <= kGraphMaxFrames;
+    if (want_graph && e->graph_exec && e->graph_nimg == nimg && e->graph_w == w && e->graph_h == h) {
+        ORBGPU_HIP_CHECK(hipGraphLaunch(e->graph_exec, st));
+        e->last_nimg = nimg;  // what orbgpu_extract_batch_device notes on the host
+        e->halo_full = false;
+    } else if (want_graph) {
+        drop_graph(e);
+        bool captured = false;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            rc = enqueue();
+            hipGraph_t g = nullptr;
+            const hipError_t end = hipStreamEndCapture(st, &g);
+            if (rc == ORBGPU_OK && end == hipSuccess && g && hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                e->graph = g;
+                e->graph_nimg = nimg; e->graph_w = w; e->graph_h = h;
+                captured = true;
+            } else if (g) {
+                (void)hipGraphDestroy(g);
+            }
+        }
+        (void)hipGetLastError();
+        if (captured) {
+            ORBGPU_HIP_CHECK(hipGraphLaunch(e->graph_exec, st));
+        } else {
+            e->graph_broken = true;
+            e->graph_exec = nullptr;
+            if ((rc = enqueue())) return rc;
+        }
+    } else {
+        if ((rc = enqueue())) return rc;
+    }
     ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
     if (*h_status) {
         set_error("internal capacity exceeded (status %d)", *h_status);
