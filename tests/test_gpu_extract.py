@@ -216,6 +216,35 @@ def test_batch_of_64_dense_frames(oracle):
         assert int((res[i][1] != odesc).any(axis=1).sum()) <= 0.001 * len(odesc)
 
 
+def test_frame_size_changes_on_one_handle(oracle):
+    """A handle sized for 640x480 is given smaller frames and the first size again, through the single-frame call and
+    the batch call: the tables, buffers and the replayed launch sequence follow the frame size, and every result equals
+    that of a fresh handle."""
+    big = synth.sequence(640, 480, 3, seed=41)
+    small = synth.sequence(320, 240, 2, seed=42)
+    odd = synth.sequence(411, 277, 1, seed=43)[0]
+    ex = _mk(640, 480, 1000, max_batch=2)
+
+    def fresh(img):
+        h, w = img.shape
+        return _mk(w, h, 1000)(img)
+
+    for img in (big[0], big[1], small[0], big[2], odd, small[1], big[0]):
+        k, d = ex(img)
+        rk, rd = fresh(img)
+        assert np.array_equal(k, rk) and np.array_equal(d, rd), img.shape
+    res = ex.extract_batch(small)
+    for i in range(2):
+        rk, rd = fresh(small[i])
+        assert np.array_equal(res[i][0], rk) and np.array_equal(res[i][1], rd)
+    k, d = ex(big[1])
+    rk, rd = fresh(big[1])
+    assert np.array_equal(k, rk) and np.array_equal(d, rd)
+    ok, od = oracle.Extractor(1000).extract(odd)
+    k, d = ex(odd)
+    assert len(k) == len(ok) and np.array_equal(k["x"], ok["x"]) and np.array_equal(k["y"], ok["y"])
+
+
 def test_degenerate_images(oracle):
     ex = _mk(640, 480, 1000)
     k, d = ex(np.zeros((0, 0), np.uint8))
