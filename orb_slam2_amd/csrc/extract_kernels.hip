@@ -167,13 +167,12 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
         // the row and, for rows next to the top / bottom edge, its reflect-101 image in the halo (tabulated)
         const int ym = (yv.pad & 0xFFFF) - 32;
         uint8_t *q = D + y * gd.pitch, *qm = D + ym * gd.pitch;  // 32-bit scalar row offsets (a frame's pyramid is < 2 GiB)
-        if (n >= 2) {
+        if (n >= 1) {
+            // an odd width's last lane also writes the first halo column (a copy of the last pixel): nothing in the
+            // extraction reads it, and k_halo_sides overwrites it when a caller asks for the border
             const uint16_t v = (uint16_t)(p0 | (p1 << 8));
             *reinterpret_cast<uint16_t *>(q) = v;
             if (ym != y) *reinterpret_cast<uint16_t *>(qm) = v;
-        } else if (n == 1) {
-            *q = (uint8_t)p0;
-            if (ym != y) *qm = (uint8_t)p0;
         }
     }
 }
