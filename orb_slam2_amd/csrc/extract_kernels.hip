@@ -1179,11 +1179,18 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 #else
 #define ORB_DSTAMP(k_) do { } while (0)
 #endif
+    // the per-level counts of the frame: uniform loads, all in flight at once (entries past nlevels belong to later
+    // frames or to the padding behind the last one: masked wherever they are used)
+    int n[ORBGPU_MAX_LEVELS];
+#pragma unroll
+    for (int k = 0; k < ORBGPU_MAX_LEVELS; k++) n[k] = sc[k];
     {
         // most slots are empty (a level rarely fills its quota): leave on scalar arithmetic alone when none of
         // this wave's slots holds a keypoint
-        bool any = slot0 == 0;  // the wave of slot 0 also writes the frame's count
-        for (int k = 0; k < G.nlevels; k++) any = any || max(slot0, G.t_kp_off[k]) < min(slot0 + kDescGroup, G.t_kp_off[k] + sc[k]);
+        int any = slot0 == 0;  // the wave of slot 0 also writes the frame's count
+#pragma unroll
+        for (int k = 0; k < ORBGPU_MAX_LEVELS; k++)
+            any |= (k < G.nlevels && max(slot0, G.t_kp_off[k]) < min(slot0 + kDescGroup, G.t_kp_off[k] + n[k])) ? 1 : 0;
         if (!any) return;
     }
 
@@ -1194,9 +1201,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     float my_scale;
     {
         const int slot = slot0 + (lane & (kDescGroup - 1));
-        int n[ORBGPU_MAX_LEVELS];
-#pragma unroll
-        for (int k = 0; k < ORBGPU_MAX_LEVELS; k++) n[k] = sc[k];  // entries past nlevels belong to later frames: masked below
         int l = 0;
 #pragma unroll
         for (int k = 1; k < ORBGPU_MAX_LEVELS; k++) l += slot >= G.t_kp_off[k] ? 1 : 0;  // unused levels hold INT_MAX
