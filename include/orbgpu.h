@@ -133,7 +133,9 @@ int orbgpu_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, int3
  * next extract call on the handle.  Above and below the interior the plane
  * carries the 19 halo rows; the 19 halo columns per side, which the extraction
  * never reads, are filled by the first orbgpu_pyramid_level call with
- * border > 0 after an extraction. */
+ * border > 0 after an extraction.  blurred != 0 is refused with
+ * ORBGPU_E_UNSUPPORTED: the blurred levels are stored in 4 x 32 pixel tiles,
+ * not row by row (orbgpu_pyramid_level returns them as images). */
 int orbgpu_pyramid_level_device(orbgpu_extractor *e, int32_t frame, int32_t level,
                                 int32_t blurred, const uint8_t **d_ptr, int32_t *pitch,
                                 int32_t *w, int32_t *h);

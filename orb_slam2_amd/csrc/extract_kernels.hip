@@ -1061,15 +1061,16 @@ __global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict
     constexpr int CG = kBW / 4;  // column groups of a tile row
     const int c = tid % CG, rg = tid / CG;
     const int x = tx0 + 4 * c;
-    uint8_t *out = blur + (int64_t)f * G.pyr_frame_bytes + interior_off(g);
+    uint8_t *out = blur + (int64_t)f * G.pyr_frame_bytes + g.plane_off;  // tiled: blur_tiled_off
     const uint32_t we0 = k0 | (k1 << 16), we1 = k2 | (k3 << 16), we2 = k2 | (k1 << 16), we3 = k0;
     const uint32_t wo0 = k0 << 16, wo1 = k1 | (k2 << 16), wo2 = k3 | (k2 << 16), wo3 = k1 | (k0 << 16);
     uint4 h[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) h[k] = *reinterpret_cast<const uint4 *>(hpair + (rg * 4 + k) * kBW + 4 * c);
+    uint32_t rows8[8];
 #pragma unroll
     for (int rr = 0; rr < 8; rr++) {
-        const int y = ty0 + rg * 8 + rr, b = rr >> 1;
+        const int b = rr >> 1;
         uint32_t packed = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -1079,8 +1080,15 @@ __global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict
             else sacc = dot2_u16(p3, we3, dot2_u16(p2, we2, dot2_u16(p1, we1, dot2_u16(p0, we0, 32768u))));
             packed |= min(sacc >> 16, 255u) << (8 * q);
         }
-        // a partial last group spills at most 3 bytes into the unused margin of the blurred plane
-        if (x < g.w && y < g.h) *reinterpret_cast<uint32_t *>(out + (int64_t)y * g.pitch + x) = packed;
+        rows8[rr] = packed;
+    }
+    // the thread's 4 columns x 8 rows are 32 contiguous bytes of a tile (the first row is a multiple of 8); rows past
+    // the level's last one and the up to 3 columns past its width land in unused bytes of the level's block
+    const int y0 = ty0 + rg * 8;
+    if (x < g.w && y0 < g.h) {
+        uint4 *dst = reinterpret_cast<uint4 *>(out + blur_tiled_off(g.pitch, x, y0));
+        dst[0] = make_uint4(rows8[0], rows8[1], rows8[2], rows8[3]);
+        dst[1] = make_uint4(rows8[4], rows8[5], rows8[6], rows8[7]);
     }
 }
 
@@ -1197,7 +1205,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     // lane j < kDescGroup: geometry of slot slot0 + j (invalid slots compute on pixel (19, 19) of
     // level 0 and store nothing); every table below is read with uniform, independent loads
     int my_l = 0, my_valid = 0, my_oi = 0, my_x = kEdge, my_y = kEdge, my_resp = 0;
-    int my_pitch, my_off, my_patch;
+    int my_pitch, my_off, my_patch, my_plane;
     float my_scale;
     {
         const int slot = slot0 + (lane & (kDescGroup - 1));
@@ -1230,6 +1238,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 #pragma unroll
         for (int k = 1; k < ORBGPU_MAX_LEVELS; k++)
             if (k == my_l) { my_pitch = G.t_pitch[k]; my_off = G.t_interior[k]; my_patch = G.t_patch[k]; my_scale = G.t_scale[k]; }
+        my_plane = my_off - kEdge * my_pitch - kLeftMargin;  // the level's block: the blurred level is stored in tiles
         my_off += my_y * my_pitch + my_x;
     }
     if (__ballot(my_valid && lane < kDescGroup) == 0) return;
@@ -1307,19 +1316,25 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     int srow[6], scol[6];
 #pragma unroll
     for (int m = 0; m < 6; m++) {
+        // column-major over the patch: the blurred level is stored in 4-pixel-wide, 32-row tiles of one line each, so
+        // the 64 dwords of one load instruction (1.7 columns of 37 rows) lie in three or four lines
         const int i = min(lane + 64 * m, (2 * kBR + 1) * (kBPitch / 4) - 1);
-        srow[m] = i / (kBPitch / 4);
-        scol[m] = i - srow[m] * (kBPitch / 4);
+        scol[m] = i / (2 * kBR + 1);
+        srow[m] = i - scol[m] * (2 * kBR + 1);
     }
     uint32_t *pw = reinterpret_cast<uint32_t *>(patch[wv]);
     const uint8_t *pb = patch[wv];
     uint32_t pre[6];
-    {
-        const int pitch = __builtin_amdgcn_readlane(my_pitch, 0), off = __builtin_amdgcn_readlane(my_off, 0);
-        const uint8_t *c = fblur + off - kBR * pitch - kBR - ((off - kBR) & 3);
+    // dword m of keypoint j's patch: columns (x - 18 rounded down to 4) + 4 scol .., row y - 18 + srow, in the tiled plane
+    auto patch_loads = [&](int j, uint32_t (&dst)[6]) {
+        const int pitch = __builtin_amdgcn_readlane(my_pitch, j), kx = __builtin_amdgcn_readlane(my_x, j);
+        const int ky = __builtin_amdgcn_readlane(my_y, j);
+        const uint8_t *c = fblur + __builtin_amdgcn_readlane(my_plane, j);
+        const int xb = (kx - kBR) & ~3, yb = ky - kBR;
 #pragma unroll
-        for (int m = 0; m < 6; m++) pre[m] = *reinterpret_cast<const uint32_t *>(c + srow[m] * pitch + 4 * scol[m]);
-    }
+        for (int m = 0; m < 6; m++) dst[m] = *reinterpret_cast<const uint32_t *>(c + blur_tiled_off(pitch, xb + 4 * scol[m], yb + srow[m]));
+    };
+    patch_loads(0, pre);
     // the pattern as floats, once per wave
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
@@ -1328,12 +1343,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 #pragma unroll
         for (int m = 0; m < 6; m++) pw[srow[m] * (kBPitch / 4) + scol[m]] = pre[m];
         const int ox = (__builtin_amdgcn_readlane(my_off, j) - kBR) & 3;
-        if (j + 1 < kDescGroup) {
-            const int pitch = __builtin_amdgcn_readlane(my_pitch, j + 1), off = __builtin_amdgcn_readlane(my_off, j + 1);
-            const uint8_t *c = fblur + off - kBR * pitch - kBR - ((off - kBR) & 3);
-#pragma unroll
-            for (int m = 0; m < 6; m++) pre[m] = *reinterpret_cast<const uint32_t *>(c + srow[m] * pitch + 4 * scol[m]);
-        }
+        if (j + 1 < kDescGroup) patch_loads(j + 1, pre);
         __builtin_amdgcn_wave_barrier();
         const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_a), j));
         const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_b), j));

@@ -711,6 +711,10 @@ int orbgpu_pyramid_level_device(orbgpu_extractor *e, int32_t frame, int32_t leve
         set_error("orbgpu_pyramid_level: no such frame/level");
         return ORBGPU_E_INVALID;
     }
+    if (blurred && d_ptr) {
+        set_error("the blurred levels are stored in tiles: no row-major device view (use orbgpu_pyramid_level)");
+        return ORBGPU_E_UNSUPPORTED;
+    }
     const LevelGeom &g = e->G.lv[level];
     const uint8_t *base = (const uint8_t *)(blurred ? e->blur.p : e->pyr.p);
     if (d_ptr) *d_ptr = base + (int64_t)frame * e->G.pyr_frame_bytes + interior_off(g);
@@ -725,7 +729,7 @@ int orbgpu_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, int3
 {
     const uint8_t *src;
     int32_t pitch, lw, lh;
-    int rc = orbgpu_pyramid_level_device(e, frame, level, blurred, &src, &pitch, &lw, &lh);
+    int rc = orbgpu_pyramid_level_device(e, frame, level, 0, &src, &pitch, &lw, &lh);  // sizes; the blurred level is read below
     if (rc) return rc;
     if (border < 0 || border > kEdge || (blurred && border != 0)) {
         set_error("border must be 0..19 (0 for blurred levels)");
@@ -742,6 +746,16 @@ int orbgpu_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, int3
         e->halo_full = true;
     }
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (blurred) {
+        // the blurred level is stored in tiles of 4 x 32 pixels (blur_tiled_off): fetch the level's block and put the rows together
+        const LevelGeom &g = e->G.lv[level];
+        std::vector<uint8_t> blk((size_t)g.pitch * (g.h + 2 * kEdge));
+        ORBGPU_HIP_CHECK(hipMemcpy(blk.data(), (const uint8_t *)e->blur.p + (int64_t)frame * e->G.pyr_frame_bytes + g.plane_off, blk.size(),
+                                   hipMemcpyDeviceToHost));
+        for (int y = 0; y < lh; y++)
+            for (int x = 0; x < lw; x++) dst[(size_t)y * dst_stride + x] = blk[(size_t)blur_tiled_off(g.pitch, x, y)];
+        return ORBGPU_OK;
+    }
     ORBGPU_HIP_CHECK(hipMemcpy2D(dst, dst_stride, src - (int64_t)border * pitch - border, pitch, lw + 2 * border,
                                  lh + 2 * border, hipMemcpyDeviceToHost));
     return ORBGPU_OK;

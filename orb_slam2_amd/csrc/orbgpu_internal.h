@@ -75,6 +75,17 @@ struct QNode {
 
 __host__ __device__ inline int64_t interior_off(const LevelGeom &g) { return g.plane_off + (int64_t)kEdge * g.pitch + kLeftMargin; }
 
+// The blurred levels are kept in tiles of 4 x 32 pixels = one 128-byte line each (a pixel column group of four next
+// to the same group of the next row), so that the 37 x 37 patch of a descriptor touches about 21 lines instead of 48:
+// the descriptor kernel is bound by the lines it pulls into L1.  A level's tiles fill the block its row-major plane
+// would (ceil32(h) <= h + 2 * kEdge rows): byte offset of interior pixel (x, y) from the level's plane_off; the
+// pitch is a multiple of 64.  Eight rows of a column group that start at a multiple of 8 are 32 contiguous bytes.
+__host__ __device__ inline int32_t blur_tiled_off(int32_t pitch, int32_t x, int32_t y)
+{
+    const int32_t X = x + kLeftMargin;
+    return ((((y >> 5) * (pitch >> 2) + (X >> 2)) << 7) + ((y & 31) << 2)) + (X & 3);
+}
+
 void set_error(const char *fmt, ...);
 
 // Grids are (blocks, frames).  Workgroups are dealt to the 8 XCDs round-robin in
