@@ -648,8 +648,6 @@ __global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
             if (k < e) rec = P.grec[k];
             continue;
         }
-        const uint4 d0 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k];
-        const uint4 d1 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k + 1];
         const int4 rec_next = P.grec[min(k + 1, e - 1)];
         const int oct = rec.z, t = rec.w;
         bool ok = true;
@@ -666,6 +664,10 @@ __global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
         rec = rec_next;
         uint32_t key = kNoCand;
         if (ok) {
+            // only the lanes whose entry passed the gates fetch its descriptor: the loads of a wave are priced by the
+            // lines they touch, and every lane's entry lies in a line of its own
+            const uint4 d0 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k];
+            const uint4 d1 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k + 1];
             const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
                              __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
             if (cand_useful(A, dist)) {
