@@ -604,11 +604,11 @@ __global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
 // holds few grid entries (a handful at tracking radii), so a lane walks its own window -- grid column after grid
 // column, each a contiguous run of grid entries, i.e. the reference's candidate order -- and keeps its kTopK
 // best candidates as a sorted list in registers; the wave runs as long as its busiest lane.
-__global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
+// cs / grec / gdesc: the pair's cell starts, grid records and grid-ordered descriptors, in global memory or staged in LDS.
+__device__ __forceinline__ void lanes_query(const MatchArgs &A, const PairCtx &P, int i, const int32_t *cs, const int4 *grec,
+                                            const uint4 *gdesc)
 {
-    const int pair = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x, mode = A.mode;
-    const PairCtx P = make_ctx(A, pair);
-    if (i >= P.nq) return;
+    const int mode = A.mode;
     const orbgpu_wquery q = P.Q[i];
     uint32_t c[kTopK];  // distance << 20 | train index, ascending distance, equal distances in scan order
 #pragma unroll
@@ -631,8 +631,8 @@ __global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
     int col = live ? c0 : c1 + 1, k = 0, e = 0;
     int kn = 0, en = 0;  // run of column `col`
     if (col <= c1) {
-        kn = P.cell_start[col * ORBGPU_GRID_ROWS + r0];
-        en = P.cell_start[col * ORBGPU_GRID_ROWS + r1 + 1];
+        kn = cs[col * ORBGPU_GRID_ROWS + r0];
+        en = cs[col * ORBGPU_GRID_ROWS + r1 + 1];
     }
     int4 rec = make_int4(0, 0, 0, 0);
     while (true) {
@@ -642,13 +642,13 @@ __global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
             e = en;
             col++;
             if (col <= c1) {
-                kn = P.cell_start[col * ORBGPU_GRID_ROWS + r0];
-                en = P.cell_start[col * ORBGPU_GRID_ROWS + r1 + 1];
+                kn = cs[col * ORBGPU_GRID_ROWS + r0];
+                en = cs[col * ORBGPU_GRID_ROWS + r1 + 1];
             }
-            if (k < e) rec = P.grec[k];
+            if (k < e) rec = grec[k];
             continue;
         }
-        const int4 rec_next = P.grec[min(k + 1, e - 1)];
+        const int4 rec_next = grec[min(k + 1, e - 1)];
         const int oct = rec.z, t = rec.w;
         bool ok = true;
         if (check) {
@@ -666,8 +666,8 @@ __global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
         if (ok) {
             // only the lanes whose entry passed the gates fetch its descriptor: the loads of a wave are priced by the
             // lines they touch, and every lane's entry lies in a line of its own
-            const uint4 d0 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k];
-            const uint4 d1 = reinterpret_cast<const uint4 *>(P.gdesc)[2 * (size_t)k + 1];
+            const uint4 d0 = gdesc[2 * (size_t)k];
+            const uint4 d1 = gdesc[2 * (size_t)k + 1];
             const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
                              __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
             if (cand_useful(A, dist)) {
@@ -694,6 +694,48 @@ __global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
 #pragma unroll
     for (int s = 0; s < kTopK / 4; s++) out[s] = make_uint4(c[4 * s], c[4 * s + 1], c[4 * s + 2], c[4 * s + 3]);
     P.ncand[i] = npass;
+}
+
+
+__global__ __launch_bounds__(64) void k_window_topk_lanes(MatchArgs A)
+{
+    const int pair = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+    const PairCtx P = make_ctx(A, pair);
+    if (i >= P.nq) return;
+    lanes_query(A, P, i, P.cell_start, P.grec, reinterpret_cast<const uint4 *>(P.gdesc));
+}
+
+// The same walk with the pair's grid staged in LDS: one workgroup per pair copies the cell starts, the records and
+// the descriptors of the train frame (coalesced, once), then every lane walks its window out of LDS.  Walking global
+// memory, the 64 lanes of a load touch 64 different lines, and the wave is priced by those lines.
+constexpr int kStagedThreads = 512;
+__host__ __device__ inline size_t staged_lds_bytes(int t_cap) { return (size_t)t_cap * 48 + (size_t)(kCells + 1 + 3) / 4 * 16; }
+
+__global__ __launch_bounds__(kStagedThreads) void k_window_topk_staged(MatchArgs A)
+{
+    extern __shared__ __align__(16) uint8_t staged[];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const PairCtx P = make_ctx(A, pair);
+    uint4 *l_desc = reinterpret_cast<uint4 *>(staged);                                // [2 * t_cap]
+    int4 *l_rec = reinterpret_cast<int4 *>(staged + (size_t)A.t_cap * 32);            // [t_cap]
+    int32_t *l_cs = reinterpret_cast<int32_t *>(staged + (size_t)A.t_cap * 48);       // [kCells + 1]
+    const int ng = P.cell_start[kCells];  // entries of the grid (keypoints inside the bounds)
+    for (int k = tid; k < 2 * ng; k += kStagedThreads) l_desc[k] = reinterpret_cast<const uint4 *>(P.gdesc)[k];
+    for (int k = tid; k < ng; k += kStagedThreads) l_rec[k] = P.grec[k];
+    for (int k = tid; k <= kCells; k += kStagedThreads) l_cs[k] = P.cell_start[k];
+    __syncthreads();
+    // A lane takes a query from the front and its mirror from the back of the list: the extractor lists keypoints
+    // level by level and the windows grow with the level, so the two together cost about the same for every lane,
+    // and neighbouring lanes still walk windows of like size.
+    const int nq = P.nq, half = (nq + 1) >> 1;
+    for (int t = tid; t < half; t += kStagedThreads) {
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const int i = h ? nq - 1 - t : t;
+            if (h && i == t) break;
+            lanes_query(A, P, i, l_cs, l_rec, l_desc);
+        }
+    }
 }
 
 // Acceptance rules of the four matchers, given the best two available candidates.
@@ -955,6 +997,8 @@ int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
     // a lane per query pays once there are enough queries to fill the chip; below that the half-wave scan is quicker
     if (A.mode == 4 || A.mode == 5 || (int64_t)A.q_cap * npairs < 65536)
         hipLaunchKernelGGL(k_window_topk, dim3((A.q_cap + 7) / 8, npairs), dim3(256), 0, st, A);
+    else if (staged_lds_bytes(A.t_cap) <= 64 * 1024)  // two workgroups per CU
+        hipLaunchKernelGGL(k_window_topk_staged, dim3(npairs), dim3(kStagedThreads), staged_lds_bytes(A.t_cap), st, A);
     else
         hipLaunchKernelGGL(k_window_topk_lanes, dim3((A.q_cap + 63) / 64, npairs), dim3(64), 0, st, A);
     // selection state in LDS when it fits (6 words per query + 1 per train keypoint)
