@@ -635,9 +635,10 @@ __device__ __forceinline__ void lanes_query(const MatchArgs &A, const PairCtx &P
         en = cs[col * ORBGPU_GRID_ROWS + r1 + 1];
     }
     int4 rec = make_int4(0, 0, 0, 0);
-    while (true) {
-        if (k >= e) {  // next grid column of the window
-            if (col > c1) break;
+    // opens the next non-empty grid column of the window (a short loop of its own: an iteration of the walk below
+    // pays for its whole body, so it is spent on entries only)
+    auto next_column = [&]() {
+        while (k >= e && col <= c1) {
             k = kn;
             e = en;
             col++;
@@ -645,10 +646,12 @@ __device__ __forceinline__ void lanes_query(const MatchArgs &A, const PairCtx &P
                 kn = cs[col * ORBGPU_GRID_ROWS + r0];
                 en = cs[col * ORBGPU_GRID_ROWS + r1 + 1];
             }
-            if (k < e) rec = grec[k];
-            continue;
         }
-        const int4 rec_next = grec[min(k + 1, e - 1)];
+        if (k < e) rec = grec[k];
+    };
+    next_column();
+    while (k < e) {
+        int4 rec_next = grec[min(k + 1, e - 1)];
         const int oct = rec.z, t = rec.w;
         bool ok = true;
         if (check) {
@@ -661,7 +664,6 @@ __device__ __forceinline__ void lanes_query(const MatchArgs &A, const PairCtx &P
             if (ok && mode < 2 && P.UR && P.UR[t] > 0 && fabsf(__fsub_rn(q.ur, P.UR[t])) > r) ok = false;
             if (ok && mode == 6 && A.chi2_gate) ok = reprojection_gate(A, P, q, rec, t);
         }
-        rec = rec_next;
         uint32_t key = kNoCand;
         if (ok) {
             // only the lanes whose entry passed the gates fetch its descriptor: the loads of a wave are priced by the
@@ -676,6 +678,8 @@ __device__ __forceinline__ void lanes_query(const MatchArgs &A, const PairCtx &P
             }
         }
         k++;
+        rec = rec_next;
+        if (k >= e) next_column();
         // insert behind the entries of smaller or equal distance; slots are visited only while some lane of the
         // wave still has something to place (a lane is through once it carries an empty slot's content)
         uint32_t carry = key;
