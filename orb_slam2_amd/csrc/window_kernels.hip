@@ -129,11 +129,13 @@ __device__ __forceinline__ PairCtx make_ctx(const MatchArgs &A, int pair)
 // ---------------------------------------------------------------------------
 // grid
 // ---------------------------------------------------------------------------
+constexpr int kGridLdsIdx = 4096;  // keypoints of a frame whose grid order is sorted in LDS
 __global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
 {
     __shared__ int cs[kCells + 1];
     __shared__ int cursor[kCells];
     __shared__ int scan_lds[33];
+    __shared__ int32_t gidx_lds[kGridLdsIdx];
     const int pair = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x;
     const PairCtx P = make_ctx(A, pair);
     const int n2 = P.n2;
@@ -159,37 +161,42 @@ __global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
         if (tid == 0) cs[kCells] = carry;
     }
     __syncthreads();
-    // fetch-and-add gives an arbitrary in-cell order ...
-    int32_t *gidx = P.head;  // free until the resolver runs
-    for (int i = tid; i < n2; i += nt_) {
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.minX), P.invW));
-        const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.minY), P.invH));
-        if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS) {
-            const int cidx = px * ORBGPU_GRID_ROWS + py;
-            gidx[cs[cidx] + atomicAdd(&cursor[cidx], 1)] = i;
+    // fetch-and-add gives an arbitrary in-cell order, restored below.  The index list lives in LDS when the frame's
+    // keypoints fit (every access of the per-cell sort would otherwise be a round trip to global memory), else in
+    // the head array, which is free until the resolver runs.
+    auto order_and_write = [&](auto *gidx) {
+        for (int i = tid; i < n2; i += nt_) {
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.minX), P.invW));
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.minY), P.invH));
+            if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS) {
+                const int cidx = px * ORBGPU_GRID_ROWS + py;
+                gidx[cs[cidx] + atomicAdd(&cursor[cidx], 1)] = i;
+            }
         }
-    }
-    __syncthreads();
-    // ... so restore insertion (ascending index) order inside every cell
-    for (int cidx = tid; cidx < kCells; cidx += nt_) {
-        const int s = cs[cidx], e = cs[cidx + 1];
-        for (int i = s + 1; i < e; i++) {
-            const int v = gidx[i];
-            int j = i - 1;
-            while (j >= s && gidx[j] > v) { gidx[j + 1] = gidx[j]; j--; }
-            gidx[j + 1] = v;
+        __syncthreads();
+        // ... so restore insertion (ascending index) order inside every cell
+        for (int cidx = tid; cidx < kCells; cidx += nt_) {
+            const int s = cs[cidx], e = cs[cidx + 1];
+            for (int i = s + 1; i < e; i++) {
+                const int v = gidx[i];
+                int j = i - 1;
+                while (j >= s && gidx[j] > v) { gidx[j + 1] = gidx[j]; j--; }
+                gidx[j + 1] = v;
+            }
         }
-    }
-    __syncthreads();
-    for (int i = tid; i <= kCells; i += nt_) P.cell_start[i] = cs[i];
-    const int ng = cs[kCells];
-    for (int k = tid; k < ng; k += nt_) {
-        const int t = gidx[k];
-        const orbgpu_keypoint kp = P.K2[t];
-        P.grec[k] = make_int4(__float_as_int(kp.x), __float_as_int(kp.y), kp.octave, t);
-    }
-    // descriptors in grid order: 8 lanes copy one 32-byte descriptor
-    for (int w = tid; w < ng * 8; w += nt_) P.gdesc[w] = P.TD[(size_t)gidx[w >> 3] * 8 + (w & 7)];
+        __syncthreads();
+        for (int i = tid; i <= kCells; i += nt_) P.cell_start[i] = cs[i];
+        const int ng = cs[kCells];
+        for (int k = tid; k < ng; k += nt_) {
+            const int t = gidx[k];
+            const orbgpu_keypoint kp = P.K2[t];
+            P.grec[k] = make_int4(__float_as_int(kp.x), __float_as_int(kp.y), kp.octave, t);
+        }
+        // descriptors in grid order: 8 lanes copy one 32-byte descriptor
+        for (int w = tid; w < ng * 8; w += nt_) P.gdesc[w] = P.TD[(size_t)gidx[w >> 3] * 8 + (w & 7)];
+    };
+    if (n2 <= kGridLdsIdx) order_and_write(gidx_lds);
+    else order_and_write(P.head);
 }
 
 // ---------------------------------------------------------------------------
