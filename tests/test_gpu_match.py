@@ -374,16 +374,17 @@ def test_bruteforce_100k_properties(matcher):
     assert np.array_equal(si, np.arange(5000)) and (s1 == 0).all() and (s2 > 0).all()
 
 
-@pytest.mark.parametrize("mode,th", [(1, 15.0), (0, 9.0), (2, 30.0)])
-def test_batch_device_many_pairs(oracle, frames, mode, th):
+@pytest.mark.parametrize("mode,th,tcap", [(1, 15.0, 1100), (0, 9.0, 1100), (2, 30.0, 1100), (1, 40.0, 1500), (0, 20.0, 1400)])
+def test_batch_device_many_pairs(oracle, frames, mode, th, tcap):
     """64 pairs in one launch: batches of this size use the lane-per-query scan (single calls use the half-wave
-    scan), both must give the reference's result.  The pairs differ in query subset, radius and occupancy."""
+    scan), with the pair's grid staged in LDS when the train capacity allows (1100) and out of global memory when
+    not (1400, 1500); all must give the reference's result.  The pairs differ in query subset, radius and occupancy."""
     from orb_slam2_amd import api
     from hiputil import Hip
     m = api.ORBmatcher(0.8, True)
     sc = oracle.tables(oracle.make_params(1000))["scale"]
     b = _bounds()
-    npairs, qcap, tcap = 64, 1100, 1100
+    npairs, qcap = 64, 1100
     rng = np.random.default_rng(100 + mode)
     Q = np.zeros((npairs, qcap), api.WQUERY_DTYPE); QD = np.zeros((npairs, qcap, 32), np.uint8)
     K2 = np.zeros((npairs, tcap), api.KEYPOINT_DTYPE); D2 = np.zeros((npairs, tcap, 32), np.uint8)
