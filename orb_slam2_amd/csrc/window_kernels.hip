@@ -1015,7 +1015,9 @@ int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
     // selection state in LDS when it fits (6 words per query + 1 per train keypoint)
     const size_t state = (6 * (size_t)A.q_cap + (size_t)A.t_cap) * 4;
     const int lds_state = state <= 48 * 1024;
-    hipLaunchKernelGGL(k_window_resolve, dim3(npairs), dim3(1024), lds_state ? state : 0, st, A, lds_state);
+    // the kernel holds 128 registers: 1024 threads fill a CU, 512 let two pairs share it (a batch of pairs then runs in
+    // one round; the second query of a thread re-reads its candidates in every iteration)
+    hipLaunchKernelGGL(k_window_resolve, dim3(npairs), dim3(npairs >= 256 ? 512 : 1024), lds_state ? state : 0, st, A, lds_state);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
