@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "orbgpu_internal.h"
@@ -527,6 +529,23 @@ int orbgpu_extractor_max_keypoints(const orbgpu_extractor *e, int32_t *max_kp)
     return ORBGPU_OK;
 }
 
+// Host-side copies of a batch, frame by frame: in the calling thread for a few frames, else on up to eight threads.
+static void parallel_frames(int nimg, const std::function<void(int)> &fn)
+{
+    const int nthreads = std::min(8, nimg / 16);
+    if (nthreads < 2) {
+        for (int f = 0; f < nimg; f++) fn(f);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(nthreads);
+    for (int t = 0; t < nthreads; t++)
+        pool.emplace_back([&, t]() {
+            for (int f = t; f < nimg; f += nthreads) fn(f);
+        });
+    for (auto &th : pool) th.join();
+}
+
 static constexpr int kGraphMaxFrames = 8;  // beyond a few frames the kernels dominate and plain launches do as well
 
 static void drop_graph(orbgpu_extractor *e)
@@ -616,12 +635,15 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
     const int cap = e->G.total_kp_cap;
     uint8_t *h_in = (uint8_t *)e->h_pinned + (size_t)e->p.max_batch * cap * (sizeof(orbgpu_keypoint) + 32) + (size_t)e->p.max_batch * 4 + 64;
     // the previous call's device-to-host copies have completed (every host entry point synchronises)
-    for (int f = 0; f < nimg; f++) {
+    for (int f = 0; f < nimg; f++)
         if (!imgs[f]) { set_error("image %d is NULL", f); return ORBGPU_E_INVALID; }
-        // pageable -> pinned on the host (a 2-D copy from pageable memory stalls for milliseconds)
+    // pageable -> pinned on the host (a 2-D copy from pageable memory stalls for milliseconds); a batch is copied by
+    // a few threads, one host thread moves only a few GB/s
+    parallel_frames(nimg, [&](int f) {
         uint8_t *hin = h_in + (size_t)f * w * h;
-        for (int y = 0; y < h; y++) memcpy(hin + (size_t)y * w, imgs[f] + (size_t)y * stride, (size_t)w);
-    }
+        if (stride == w) memcpy(hin, imgs[f], (size_t)w * h);
+        else for (int y = 0; y < h; y++) memcpy(hin + (size_t)y * w, imgs[f] + (size_t)y * stride, (size_t)w);
+    });
     uint8_t *hp = (uint8_t *)e->h_pinned;
     orbgpu_keypoint *h_kps = (orbgpu_keypoint *)hp;
     uint8_t *h_desc = hp + (size_t)nimg * cap * sizeof(orbgpu_keypoint);
@@ -684,9 +706,12 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
             return ORBGPU_E_CAPACITY;
         }
         counts[f] = n;
+    }
+    parallel_frames(nimg, [&](int f) {
+        const int n = h_counts[f];
         memcpy(kps + (size_t)f * capacity, h_kps + (size_t)f * cap, (size_t)n * sizeof(orbgpu_keypoint));
         memcpy(desc + (size_t)f * capacity * 32, h_desc + (size_t)f * cap * 32, (size_t)n * 32);
-    }
+    });
     return ORBGPU_OK;
 }
 
