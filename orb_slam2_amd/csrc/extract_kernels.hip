@@ -446,6 +446,20 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     const int n = nmax, use_ini = nini > 0;
     const int count = use_ini ? nini : n;
     uint32_t *slot = slots + (int64_t)f * G.slot_frame_u32 + cu.slot_off;
+    if (n <= 64) {
+        // the usual case: the maxima fit one wave, which ranks them through lane reads instead of LDS reads
+        if (tid < 64) {
+            const uint32_t e = tid < n ? maxima[tid] : 0u;
+            const bool chosen = tid < n && (!use_ini || (e & 0x1000u));
+            const uint32_t pix = e & 0xFFFu, key = chosen ? pix : 0xFFFFu;  // the others rank behind every chosen one
+            int pos = 0;
+            for (int j = 0; j < n; j++) pos += (uint32_t)__builtin_amdgcn_readlane((int)key, j) < key ? 1 : 0;
+            if (chosen) {
+                const int y = div_small((int)pix, mdiv), x = (int)pix - (int)__umul24(y, wi);
+                if (pos < cu.cell_cap) slot[pos] = pack_cand(x + cu.x0, y + cu.y0, (int)(e >> 16));
+            }
+        }
+    } else
     for (int k = tid; k < n; k += kFastThreads) {
         const uint32_t e = maxima[k];
         if (use_ini && !(e & 0x1000u)) continue;
