@@ -1400,7 +1400,7 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     hipLaunchKernelGGL(k_pyr_copy0, dim3((((g0.w + 15) / 16) * g0.h + 255) / 256, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G_);
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
-        hipLaunchKernelGGL(k_pyr_resize, dim3(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), grid_frames(nimg)), dim3(256),
+        hipLaunchKernelGGL(k_pyr_resize, frame_grid(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), nimg), dim3(256),
                            (size_t)g.rs_rows * g.rs_pitch_dw * 4, st, pyr, G, l, xtab, ytab);
     }
     ORBGPU_HIP_CHECK(hipGetLastError());
@@ -1492,7 +1492,7 @@ int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, con
 {
     Geom G = G_;
     G.nimg = nimg;
-    hipLaunchKernelGGL(k_blur, dim3(ntiles, grid_frames(nimg)), dim3(kBlurThreads), 0, st, pyr, blur, G, tile_tab);
+    hipLaunchKernelGGL(k_blur, frame_grid(ntiles, nimg), dim3(kBlurThreads), 0, st, pyr, blur, G, tile_tab);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
@@ -1503,7 +1503,7 @@ int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t 
 {
     Geom G = G_;
     G.nimg = nimg;
-    hipLaunchKernelGGL(k_describe, dim3((G.total_kp_cap + 4 * kDescGroup - 1) / (4 * kDescGroup), grid_frames(nimg)), dim3(256), 0, st, pyr,
+    hipLaunchKernelGGL(k_describe, frame_grid((G.total_kp_cap + 4 * kDescGroup - 1) / (4 * kDescGroup), nimg), dim3(256), 0, st, pyr,
                        blur, G, sel, sel_count,
                        pattern, kps, desc, counts, capacity, status);
     ORBGPU_HIP_CHECK(hipGetLastError());

@@ -89,11 +89,11 @@ __host__ __device__ inline int32_t blur_tiled_off(int32_t pitch, int32_t x, int3
 void set_error(const char *fmt, ...);
 
 // Grids are (blocks, frames).  Workgroups are dealt to the 8 XCDs round-robin in
-// linear order; for batches of 8 or more frames the (frame, block) pair is
-// derived from the linear id so that all blocks of a frame run on one XCD and
-// share its L2 (frame % 8 picks the XCD).  The frame axis of the grid is padded
-// to a multiple of 8; padding workgroups get false.  Affects speed only.
-inline int grid_frames(int nimg) { return nimg < 8 ? nimg : (nimg + 7) & ~7; }
+// linear order; for batches of 8 or more frames the grid is (8 * blocks, frame
+// groups of 8) instead, so that all blocks of a frame run on one XCD and share
+// its L2 (frame % 8 picks the XCD) and no kernel divides to find its frame.
+// Workgroups of the frames that pad the last group get false.  Affects speed only.
+inline dim3 frame_grid(int blocks, int nimg) { return nimg < 8 ? dim3(blocks, nimg) : dim3(8 * blocks, (nimg + 7) / 8); }
 
 #ifdef __HIPCC__
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -105,9 +105,10 @@ __device__ __forceinline__ bool frame_block(int nimg, int *f, int *b)
         *b = blockIdx.x;
         return true;
     }
-    const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, j = L >> 3, q = j / gridDim.x;
-    *f = (int)(q * 8 + (L & 7));
-    *b = (int)(j - q * gridDim.x);
+    // workgroups go to the XCDs round-robin by linear index and gridDim.x is a multiple of 8: the low three bits of
+    // blockIdx.x choose the XCD, i.e. the frame within the group of eight
+    *f = (int)(blockIdx.y * 8 + (blockIdx.x & 7));
+    *b = (int)(blockIdx.x >> 3);
     return *f < nimg;
 }
 
