@@ -173,6 +173,21 @@ int orbgpu_hamming_bruteforce_device(orbgpu_matcher *m, const uint8_t *d_Q, int3
                                      const uint8_t *d_T, int32_t nt, int32_t *d_best_idx,
                                      int32_t *d_best_d, int32_t *d_second_d);
 
+/* orbgpu_hamming_bruteforce_device for callers that cannot allocate (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
+ * no counterpart in the reference.  Same arguments, same results; it calls no
+ * hipMalloc / hipFree: the per-chunk partial results live in a fixed 16 MiB
+ * array in each GPU's memory (held until the process ends; its address is looked
+ * up per device in orbgpu_matcher_create).  Limit: nq * ceil(nt / 2^20) <= 2^21
+ * (e.g. 100 000 x 100 000, or 2 M queries against up to 1 M train descriptors);
+ * beyond it the call returns ORBGPU_E_CAPACITY.  All calls on one GPU share that
+ * array: calls that overlap in time on the same GPU (different handles or
+ * streams) race and must be serialised by the caller.  Nothing in it has to
+ * start at zero: every partial result a call reads is written by that call. */
+int orbgpu_hamming_bruteforce_device_noalloc(orbgpu_matcher *m, const uint8_t *d_Q, int32_t nq,
+                                             const uint8_t *d_T, int32_t nt, int32_t *d_best_idx,
+                                             int32_t *d_best_d, int32_t *d_second_d);
+
 /* One windowed query of the SearchByProjection family: projection (u,v), search
  * radius r (already multiplied by the level scale), octave window as
  * Frame::GetFeaturesInArea takes it (src/Frame.cc:397), the query keypoint's

@@ -37,6 +37,7 @@ EXPORTS = [
     "orbgpu_debug_level_candidates", "orbgpu_debug_level_selected",
     "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync",
     "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
+    "orbgpu_hamming_bruteforce_device_noalloc",
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
     "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_in_area", "orbgpu_assign_features_to_grid",
     "orbgpu_distinctive_descriptors", "orbgpu_stereo_from_rgbd", "orbgpu_undistort_keypoints", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
@@ -94,6 +95,7 @@ def load_library():
         L.orbgpu_descriptor_distance.argtypes = [vp, vp]
         L.orbgpu_hamming_bruteforce.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
         L.orbgpu_hamming_bruteforce_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+        L.orbgpu_hamming_bruteforce_device_noalloc.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
         L.orbgpu_search_by_projection.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                   C.POINTER(i32)]
         L.orbgpu_search_by_projection_batch_device.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp,
@@ -348,6 +350,11 @@ class ORBmatcher:
         _check(self._lib.orbgpu_hamming_bruteforce_device(self._h, C.c_void_p(dQ), nq, C.c_void_p(dT), nt,
                                                           C.c_void_p(d_idx), C.c_void_p(d_d1), C.c_void_p(d_d2)),
                "orbgpu_hamming_bruteforce_device")
+
+    def bruteforce_device_noalloc(self, dQ, nq, dT, nt, d_idx, d_d1, d_d2):
+        _check(self._lib.orbgpu_hamming_bruteforce_device_noalloc(self._h, C.c_void_p(dQ), nq, C.c_void_p(dT), nt,
+                                                                  C.c_void_p(d_idx), C.c_void_p(d_d1), C.c_void_p(d_d2)),
+               "orbgpu_hamming_bruteforce_device_noalloc")
 
     def window_stats(self, pair=0):
         it, rs = C.c_int32(), C.c_int32()

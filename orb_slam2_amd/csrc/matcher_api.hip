@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "match_internal.h"
@@ -62,6 +63,38 @@ struct orbgpu_matcher {
     MBuf stage[12];  // staging for the host entry points
 };
 
+// Partial results of the allocation-free brute-force entry point: one fixed array in every
+// GPU's memory for the life of the process.  Host code never uses the array's name as an
+// address: each device's copy is looked up once with hipGetSymbolAddress while that device is
+// current (resolve_noalloc_scratch, called from orbgpu_matcher_create) and the pointer kept per
+// device.
+#define ORBGPU_NOALLOC_SCRATCH_BYTES (16u << 20)
+#define ORBGPU_NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[ORBGPU_NOALLOC_SCRATCH_BYTES];
+static void *g_noalloc_scratch[ORBGPU_NOALLOC_MAX_DEVICES];
+static std::mutex g_noalloc_mutex;
+
+// With `device` current: the address of this device's copy of `scratch`.
+static int resolve_noalloc_scratch(int device, void **out)
+{
+    if (device < 0 || device >= ORBGPU_NOALLOC_MAX_DEVICES) {
+        set_error("device %d is beyond the %d devices the allocation-free entry point serves", device, ORBGPU_NOALLOC_MAX_DEVICES);
+        return ORBGPU_E_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_scratch[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            set_error("hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
+            return ORBGPU_E_HIP;
+        }
+        g_noalloc_scratch[device] = ptr;
+    }
+    if (out) *out = g_noalloc_scratch[device];
+    return ORBGPU_OK;
+}
+
 static void choose_split(int nq, int nt, int *nsplit, int *tchunk)
 {
     // Aim at >= ~4096 workgroups so 256 CUs stay balanced; chunks of at most
@@ -104,6 +137,11 @@ int orbgpu_matcher_create(int32_t device, orbgpu_matcher **out)
         return ORBGPU_E_HIP;
     }
     m->stream = m->own_stream;
+    int rc = resolve_noalloc_scratch(device, nullptr);  // device is current here
+    if (rc != ORBGPU_OK && rc != ORBGPU_E_UNSUPPORTED) {
+        orbgpu_matcher_destroy(m);
+        return rc;
+    }
     *out = m;
     return ORBGPU_OK;
 }
@@ -162,6 +200,33 @@ int orbgpu_hamming_bruteforce_device(orbgpu_matcher *m, const uint8_t *d_Q, int3
     int rc = m->part.ensure((size_t)nsplit * nq * sizeof(uint2));
     if (rc) return rc;
     return launch_bruteforce(m->stream, d_Q, nq, d_T, nt, nsplit, tchunk, (uint2 *)m->part.p, d_best_idx, d_best_d, d_second_d);
+}
+
+// Same scan without any allocation: the per-chunk partial results go to this device's fixed
+// `scratch` array instead of a buffer the handle grows on demand.
+int orbgpu_hamming_bruteforce_device_noalloc(orbgpu_matcher *m, const uint8_t *d_Q, int32_t nq, const uint8_t *d_T, int32_t nt,
+                                             int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d)
+{
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!d_Q || !d_best_idx || !d_best_d || !d_second_d)) || (nt > 0 && !d_T)) {
+        set_error("orbgpu_hamming_bruteforce_device_noalloc: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (nq == 0) return ORBGPU_OK;
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    void *ptr = nullptr;
+    int rc = resolve_noalloc_scratch(m->device, &ptr);  // a table lookup after orbgpu_matcher_create
+    if (rc) return rc;
+    const size_t max_entries = ORBGPU_NOALLOC_SCRATCH_BYTES / sizeof(uint2);
+    int nsplit, tchunk;
+    choose_split(nq, nt, &nsplit, &tchunk);
+    // choose_split keeps nsplit * nq below 2^21 unless the query set alone (nq > 2^21) or the 2^20-descriptor cap
+    // on a chunk forces more partial results than the array holds
+    if ((size_t)nsplit * (size_t)nq > max_entries) {
+        set_error("orbgpu_hamming_bruteforce_device_noalloc: %d queries x %d train descriptors need more than the fixed %u-byte "
+                  "scratch (nq * ceil(nt / 2^20) <= %zu)", nq, nt, ORBGPU_NOALLOC_SCRATCH_BYTES, max_entries);
+        return ORBGPU_E_CAPACITY;
+    }
+    return launch_bruteforce(m->stream, d_Q, nq, d_T, nt, nsplit, tchunk, (uint2 *)ptr, d_best_idx, d_best_d, d_second_d);
 }
 
 int orbgpu_hamming_bruteforce(orbgpu_matcher *m, const uint8_t *Q, int32_t nq, const uint8_t *T, int32_t nt,
