@@ -78,6 +78,15 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e);
 int orbgpu_extractor_set_stream(orbgpu_extractor *e, void *hip_stream);
 int orbgpu_extractor_sync(orbgpu_extractor *e);
 
+/* Overflow flags of the handle's last extract call (synchronises): bit 0: the
+ * quadtree ran out of node storage; bit 1: a frame yielded more keypoints than
+ * the `capacity` of orbgpu_extract_batch_device (its outputs and counts[] are
+ * truncated to capacity).  The host-pointer entry points check the flags
+ * themselves and return ORBGPU_E_CAPACITY; the asynchronous device entry point
+ * cannot, so its callers ask here.  Every extract call starts with the flags
+ * cleared.  (No counterpart in the reference, whose std::vector outputs grow.) */
+int orbgpu_extractor_status(orbgpu_extractor *e, int32_t *flags);
+
 /* Stage timing (the reference has only wall-clock timing in its example
  * drivers, Examples/Monocular/mono_tum.cc:79-96).  When enabled every extract
  * call records HIP events between its stages on the handle's stream;
@@ -153,8 +162,23 @@ int orbgpu_debug_level_selected(orbgpu_extractor *e, int32_t frame, int32_t leve
 
 /* ---- ORBmatcher ---------------------------------------------------------- */
 
+/* A matcher context: one HIP stream plus scratch and staging buffers.  The
+ * reference builds an ORBmatcher on the stack at every call site
+ * (src/Tracking.cc:738,951,1060; src/LocalMapping.cc:215; src/LoopClosing.cc:241),
+ * so contexts are recycled: destroy parks an idle context (up to 8 per device),
+ * create takes one back, and neither then touches the HIP allocator. */
 int orbgpu_matcher_create(int32_t device, orbgpu_matcher **out);
 void orbgpu_matcher_destroy(orbgpu_matcher *m);
+/* Grid geometry of the NEXT windowed search on this handle (consumed by that one
+ * call; NULL clears it): geom6 = {build origin x, y, query origin x, y, inverse
+ * cell width, inverse cell height}.  Without it a call derives everything from
+ * its bounds4 as a Frame does (src/Frame.cc:101-102, 397-500).  A KeyFrame keeps
+ * the grid and the inverse cell sizes of the Frame it was made from but stores
+ * mnMinX / mnMinY truncated to int and uses those in GetFeaturesInArea
+ * (include/KeyFrame.h:130-133,185, src/KeyFrame.cc:37-52, 585-624): with a distorted
+ * camera the two origins differ by a fraction of a pixel, which can reorder
+ * candidates of equal distance. */
+int orbgpu_matcher_set_grid_geometry(orbgpu_matcher *m, const float *geom6);
 int orbgpu_matcher_set_stream(orbgpu_matcher *m, void *hip_stream);
 int orbgpu_matcher_sync(orbgpu_matcher *m);
 
@@ -211,7 +235,10 @@ typedef struct {
  * train frame.  uright (nullable) = mvuRight of the train frame; occupied
  * (nullable) = 1 where the train keypoint already holds a map point.  Output:
  * assign[n2] = index of the query whose map point ends up on each train
- * keypoint or -1; *nmatches = the reference's return value. */
+ * keypoint, -1 where the search left the keypoint alone, -2 where the
+ * rotation-consistency filter of modes LAST_FRAME / KEYFRAME removed a match
+ * (the reference then sets the keypoint's map point to NULL, :1513, :1642);
+ * *nmatches = the reference's return value. */
 int orbgpu_search_by_projection(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q,
                                 const uint8_t *qdesc, int32_t nq, const orbgpu_keypoint *kps2,
                                 const uint8_t *desc2, const float *uright2, int32_t n2,

@@ -259,13 +259,20 @@ def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_xy, windowS
 
 
 def search_by_projection(mode, queries, qdesc, kps2, desc2, bounds, uright2=None, occupied=None, th_dist=100,
-                         nnratio=0.8, checkOri=True):
+                         nnratio=0.8, checkOri=True, geom6=None):
+    """geom6 (optional): explicit grid geometry (build origin x, y, query origin x, y, 1/cell width, 1/cell height)
+    instead of the one derived from `bounds`: the KeyFrame case."""
     q = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
     kps2 = np.ascontiguousarray(kps2); desc2 = np.ascontiguousarray(desc2, np.uint8)
     b = np.asarray(bounds, np.float32)
     ur = None if uright2 is None else np.ascontiguousarray(uright2, np.float32)
     oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
     assign = np.zeros(max(len(kps2), 1), np.int32)
+    if geom6 is not None:
+        g = np.ascontiguousarray(geom6, np.float32)
+        n = lib().orc_search_by_projection_geom(mode, _p(q), _p(qdesc), len(q), _p(kps2), _p(desc2), _p(ur), len(kps2),
+                                                _p(g), _p(oc), _p(assign), th_dist, C.c_float(nnratio), int(checkOri))
+        return n, assign[:len(kps2)].copy()
     n = lib().orc_search_by_projection(mode, _p(q), _p(qdesc), len(q), _p(kps2), _p(desc2), _p(ur), len(kps2), _p(b),
                                        _p(oc), _p(assign), th_dist, C.c_float(nnratio), int(checkOri))
     return n, assign[:len(kps2)].copy()
@@ -300,13 +307,19 @@ def search_for_triangulation(queries, qdesc, kps2, desc2, uright2, seg_start, se
     return n, qmatch[:len(q)].copy()
 
 
-def search_in_area(queries, qdesc, kps2, desc2, bounds, uright2=None, inv_sigma2=None, chi2_gate=False, th_dist=50):
+def search_in_area(queries, qdesc, kps2, desc2, bounds, uright2=None, inv_sigma2=None, chi2_gate=False, th_dist=50,
+                   geom6=None):
     q = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
     kps2 = np.ascontiguousarray(kps2); desc2 = np.ascontiguousarray(desc2, np.uint8)
     b = np.asarray(bounds, np.float32)
     ur = None if uright2 is None else np.ascontiguousarray(uright2, np.float32)
     sg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
     qmatch = np.zeros(max(len(q), 1), np.int32)
+    if geom6 is not None:
+        g = np.ascontiguousarray(geom6, np.float32)
+        n = lib().orc_search_in_area_geom(_p(q), _p(qdesc), len(q), _p(kps2), _p(desc2), _p(ur), len(kps2), _p(g), _p(sg),
+                                          int(chi2_gate), th_dist, _p(qmatch))
+        return n, qmatch[:len(q)].copy()
     n = lib().orc_search_in_area(_p(q), _p(qdesc), len(q), _p(kps2), _p(desc2), _p(ur), len(kps2), _p(b), _p(sg), int(chi2_gate),
                                  th_dist, _p(qmatch))
     return n, qmatch[:len(q)].copy()

@@ -860,32 +860,43 @@ void orc_bruteforce(const uint8_t *Q, int nq, const uint8_t *T, int nt, int32_t 
     }
 }
 
-/* Frame::PosInGrid + AssignFeaturesToGrid (src/Frame.cc:270-293, 485-500). */
-static int pos_in_grid(const orc_keypoint *kp, const float *b, int *px, int *py)
+/* Grid geometry: geom6 = {build origin x, y, query origin x, y, inverse cell width, inverse cell height}.
+ * A Frame bins its keypoints and computes the cell range of a query with one origin (mnMinX, mnMinY) and
+ * mfGridElementWidthInv = 64 / (mnMaxX - mnMinX) (src/Frame.cc:101-102).  A KeyFrame keeps the Frame's grid
+ * and inverse cell sizes but queries with its own int-truncated mnMinX / mnMinY (include/KeyFrame.h:185,
+ * src/KeyFrame.cc:37-52, 585-624). */
+void orc_geom_from_bounds(const float *b, float *geom6)
 {
-    const float invW = (float)ORC_GRID_COLS / (b[2] - b[0]);
-    const float invH = (float)ORC_GRID_ROWS / (b[3] - b[1]);
-    *px = (int)roundf((kp->x - b[0]) * invW);
-    *py = (int)roundf((kp->y - b[1]) * invH);
+    geom6[0] = geom6[2] = b[0];
+    geom6[1] = geom6[3] = b[1];
+    geom6[4] = (float)ORC_GRID_COLS / (b[2] - b[0]);
+    geom6[5] = (float)ORC_GRID_ROWS / (b[3] - b[1]);
+}
+
+/* Frame::PosInGrid + AssignFeaturesToGrid (src/Frame.cc:270-293, 485-500). */
+static int pos_in_grid(const orc_keypoint *kp, const float *g, int *px, int *py)
+{
+    *px = (int)roundf((kp->x - g[0]) * g[4]);
+    *py = (int)roundf((kp->y - g[1]) * g[5]);
     if (*px < 0 || *px >= ORC_GRID_COLS || *py < 0 || *py >= ORC_GRID_ROWS) return 0;
     return 1;
 }
 
-void orc_grid_build(const orc_keypoint *kps, int n, const float *bounds4, int32_t *cell_start,
-                    int32_t *cell_items)
+void orc_grid_build_geom(const orc_keypoint *kps, int n, const float *geom6, int32_t *cell_start,
+                         int32_t *cell_items)
 {
     const int NC = ORC_GRID_COLS * ORC_GRID_ROWS;
     int32_t *cnt = (int32_t *)calloc((size_t)NC + 1, sizeof(int32_t));
     for (int i = 0; i < n; i++) {
         int px, py;
-        if (pos_in_grid(&kps[i], bounds4, &px, &py)) cnt[px * ORC_GRID_ROWS + py]++;
+        if (pos_in_grid(&kps[i], geom6, &px, &py)) cnt[px * ORC_GRID_ROWS + py]++;
     }
     int32_t acc = 0;
     for (int c = 0; c < NC; c++) { cell_start[c] = acc; acc += cnt[c]; cnt[c] = 0; }
     cell_start[NC] = acc;
     for (int i = 0; i < n; i++) {
         int px, py;
-        if (pos_in_grid(&kps[i], bounds4, &px, &py)) {
+        if (pos_in_grid(&kps[i], geom6, &px, &py)) {
             int c = px * ORC_GRID_ROWS + py;
             cell_items[cell_start[c] + cnt[c]++] = i;
         }
@@ -893,24 +904,32 @@ void orc_grid_build(const orc_keypoint *kps, int n, const float *bounds4, int32_
     free(cnt);
 }
 
-/* Frame::GetFeaturesInArea (src/Frame.cc:397-474). */
-int orc_features_in_area(const orc_keypoint *kps, const float *b, const int32_t *cell_start,
-                         const int32_t *cell_items, float x, float y, float r, int minLevel,
-                         int maxLevel, int32_t *out, int cap)
+void orc_grid_build(const orc_keypoint *kps, int n, const float *bounds4, int32_t *cell_start,
+                    int32_t *cell_items)
 {
-    const float invW = (float)ORC_GRID_COLS / (b[2] - b[0]);
-    const float invH = (float)ORC_GRID_ROWS / (b[3] - b[1]);
+    float g[6];
+    orc_geom_from_bounds(bounds4, g);
+    orc_grid_build_geom(kps, n, g, cell_start, cell_items);
+}
+
+/* Frame::GetFeaturesInArea (src/Frame.cc:397-474); KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:585-624) with
+ * minLevel = maxLevel = -1. */
+int orc_features_in_area_geom(const orc_keypoint *kps, const float *g, const int32_t *cell_start,
+                              const int32_t *cell_items, float x, float y, float r, int minLevel,
+                              int maxLevel, int32_t *out, int cap)
+{
+    const float invW = g[4], invH = g[5];
     int n = 0;
-    int c0 = (int)floorf((x - b[0] - r) * invW);
+    int c0 = (int)floorf((x - g[2] - r) * invW);
     if (c0 < 0) c0 = 0;
     if (c0 >= ORC_GRID_COLS) return 0;
-    int c1 = (int)ceilf((x - b[0] + r) * invW);
+    int c1 = (int)ceilf((x - g[2] + r) * invW);
     if (c1 > ORC_GRID_COLS - 1) c1 = ORC_GRID_COLS - 1;
     if (c1 < 0) return 0;
-    int r0 = (int)floorf((y - b[1] - r) * invH);
+    int r0 = (int)floorf((y - g[3] - r) * invH);
     if (r0 < 0) r0 = 0;
     if (r0 >= ORC_GRID_ROWS) return 0;
-    int r1 = (int)ceilf((y - b[1] + r) * invH);
+    int r1 = (int)ceilf((y - g[3] + r) * invH);
     if (r1 > ORC_GRID_ROWS - 1) r1 = ORC_GRID_ROWS - 1;
     if (r1 < 0) return 0;
     const int check = (minLevel > 0) || (maxLevel >= 0);
@@ -931,6 +950,15 @@ int orc_features_in_area(const orc_keypoint *kps, const float *b, const int32_t 
             }
         }
     return n;
+}
+
+int orc_features_in_area(const orc_keypoint *kps, const float *b, const int32_t *cell_start,
+                         const int32_t *cell_items, float x, float y, float r, int minLevel,
+                         int maxLevel, int32_t *out, int cap)
+{
+    float g[6];
+    orc_geom_from_bounds(b, g);
+    return orc_features_in_area_geom(kps, g, cell_start, cell_items, x, y, r, minLevel, maxLevel, out, cap);
 }
 
 /* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1661-1704). */
@@ -1049,6 +1077,18 @@ int orc_search_by_projection(int mode, const orc_wquery *q, const uint8_t *qdesc
                              const uint8_t *occupied, int32_t *assign, int th_dist,
                              float nnratio, int checkOri)
 {
+    float g[6];
+    orc_geom_from_bounds(bounds4, g);
+    return orc_search_by_projection_geom(mode, q, qdesc, nq, kps2, desc2, uright2, n2, g, occupied, assign, th_dist,
+                                         nnratio, checkOri);
+}
+
+int orc_search_by_projection_geom(int mode, const orc_wquery *q, const uint8_t *qdesc, int nq,
+                                  const orc_keypoint *kps2, const uint8_t *desc2,
+                                  const float *uright2, int n2, const float *geom6,
+                                  const uint8_t *occupied, int32_t *assign, int th_dist,
+                                  float nnratio, int checkOri)
+{
     int nmatches = 0;
     int32_t *cs = (int32_t *)malloc(sizeof(int32_t) * (ORC_GRID_COLS * ORC_GRID_ROWS + 1));
     int32_t *ci = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
@@ -1056,14 +1096,14 @@ int orc_search_by_projection(int mode, const orc_wquery *q, const uint8_t *qdesc
     uint8_t *occ = (uint8_t *)malloc((size_t)(n2 > 0 ? n2 : 1));
     ivec hist[ORC_HISTO_LENGTH];
     memset(hist, 0, sizeof(hist));
-    orc_grid_build(kps2, n2, bounds4, cs, ci);
+    orc_grid_build_geom(kps2, n2, geom6, cs, ci);
     for (int i = 0; i < n2; i++) { assign[i] = -1; occ[i] = occupied ? occupied[i] : 0; }
 
     for (int i = 0; i < nq; i++) {
         if (!(q[i].flags & 1)) continue;
         const float r = q[i].r;
-        int nc = orc_features_in_area(kps2, bounds4, cs, ci, q[i].u, q[i].v, r, q[i].minLevel,
-                                      q[i].maxLevel, cand, n2);
+        int nc = orc_features_in_area_geom(kps2, geom6, cs, ci, q[i].u, q[i].v, r, q[i].minLevel,
+                                           q[i].maxLevel, cand, n2);
         if (nc == 0) continue;
         int bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, bestIdx = -1;
         for (int k = 0; k < nc; k++) {
@@ -1101,7 +1141,9 @@ int orc_search_by_projection(int mode, const orc_wquery *q, const uint8_t *qdesc
         orc_three_maxima(sizes, ORC_HISTO_LENGTH, &i1_, &i2_, &i3_);
         for (int i = 0; i < ORC_HISTO_LENGTH; i++) {
             if (i == i1_ || i == i2_ || i == i3_) continue;
-            for (int j = 0; j < hist[i].n; j++) { assign[hist[i].v[j]] = -1; nmatches--; }
+            /* the reference sets the keypoint's map point to NULL here (:1513, :1642): -2 = "cleared", as
+             * distinct from -1 = "never touched" (an entry that held a map point without observations keeps it) */
+            for (int j = 0; j < hist[i].n; j++) { assign[hist[i].v[j]] = -2; nmatches--; }
         }
     }
     for (int i = 0; i < ORC_HISTO_LENGTH; i++) free(hist[i].v);
@@ -1230,17 +1272,26 @@ int orc_search_in_area(const orc_wquery *q, const uint8_t *qdesc, int nq, const 
                        const uint8_t *desc2, const float *uright2, int n2, const float *bounds4,
                        const float *inv_sigma2, int chi2_gate, int th_dist, int32_t *qmatch)
 {
+    float g[6];
+    orc_geom_from_bounds(bounds4, g);
+    return orc_search_in_area_geom(q, qdesc, nq, kps2, desc2, uright2, n2, g, inv_sigma2, chi2_gate, th_dist, qmatch);
+}
+
+int orc_search_in_area_geom(const orc_wquery *q, const uint8_t *qdesc, int nq, const orc_keypoint *kps2,
+                            const uint8_t *desc2, const float *uright2, int n2, const float *geom6,
+                            const float *inv_sigma2, int chi2_gate, int th_dist, int32_t *qmatch)
+{
     int nmatches = 0;
     int32_t *cs = (int32_t *)malloc(sizeof(int32_t) * (ORC_GRID_COLS * ORC_GRID_ROWS + 1));
     int32_t *ci = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
     int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
-    orc_grid_build(kps2, n2, bounds4, cs, ci);
+    orc_grid_build_geom(kps2, n2, geom6, cs, ci);
     for (int i = 0; i < nq; i++) {
         qmatch[i] = -1;
         if (!(q[i].flags & 1)) continue;
         const float u = q[i].u, v = q[i].v, ur = q[i].ur;
         /* KeyFrame::GetFeaturesInArea has no level filter; the callers apply [predicted-1, predicted] right after */
-        const int nc = orc_features_in_area(kps2, bounds4, cs, ci, u, v, q[i].r, -1, -1, cand, n2);
+        const int nc = orc_features_in_area_geom(kps2, geom6, cs, ci, u, v, q[i].r, -1, -1, cand, n2);
         int bestDist = 256, bestIdx = -1;
         for (int k = 0; k < nc; k++) {
             const int idx = cand[k];

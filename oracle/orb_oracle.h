@@ -118,6 +118,15 @@ int orc_features_in_area(const orc_keypoint *kps, const float *bounds4,
                          const int32_t *cell_start, const int32_t *cell_items, float x,
                          float y, float r, int minLevel, int maxLevel, int32_t *out, int cap);
 
+/* The same with an explicit grid geometry geom6 = {build origin x, y, query origin x, y, inverse cell width,
+ * inverse cell height}: a KeyFrame keeps its Frame's grid and inverse cell sizes but queries with int-truncated
+ * bounds (include/KeyFrame.h:185, src/KeyFrame.cc:37-52, 585-624). */
+void orc_geom_from_bounds(const float *bounds4, float *geom6);
+void orc_grid_build_geom(const orc_keypoint *kps, int n, const float *geom6, int32_t *cell_start, int32_t *cell_items);
+int orc_features_in_area_geom(const orc_keypoint *kps, const float *geom6, const int32_t *cell_start,
+                              const int32_t *cell_items, float x, float y, float r, int minLevel, int maxLevel,
+                              int32_t *out, int cap);
+
 /* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1661-1704) on bin sizes. */
 void orc_three_maxima(const int *sizes, int L, int *ind1, int *ind2, int *ind3);
 
@@ -179,6 +188,15 @@ int orc_search_for_triangulation(const orc_wquery *q, const uint8_t *qdesc, int 
 int orc_search_in_area(const orc_wquery *q, const uint8_t *qdesc, int nq, const orc_keypoint *kps2,
                        const uint8_t *desc2, const float *uright2, int n2, const float *bounds4,
                        const float *inv_sigma2, int chi2_gate, int th_dist, int32_t *qmatch);
+/* Both with an explicit grid geometry (see orc_grid_build_geom). */
+int orc_search_by_projection_geom(int mode, const orc_wquery *q, const uint8_t *qdesc, int nq,
+                                  const orc_keypoint *kps2, const uint8_t *desc2, const float *uright2, int n2,
+                                  const float *geom6, const uint8_t *occupied, int32_t *assign, int th_dist,
+                                  float nnratio, int checkOri);
+int orc_search_in_area_geom(const orc_wquery *q, const uint8_t *qdesc, int nq, const orc_keypoint *kps2,
+                            const uint8_t *desc2, const float *uright2, int n2, const float *geom6,
+                            const float *inv_sigma2, int chi2_gate, int th_dist, int32_t *qmatch);
+
 
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:297-334) for map points whose
  * observations are desc[start[p] .. start[p+1]).  best_idx[p] relative to start[p] (-1: none). */

@@ -31,11 +31,11 @@ MODE_LOCAL_MAP, MODE_LAST_FRAME, MODE_KEYFRAME = 0, 1, 2
 EXPORTS = [
     "orbgpu_last_error", "orbgpu_device_count",
     "orbgpu_extractor_create", "orbgpu_extractor_destroy", "orbgpu_extractor_set_stream", "orbgpu_extractor_sync",
-    "orbgpu_extractor_profile", "orbgpu_extractor_stage_times",
+    "orbgpu_extractor_status", "orbgpu_extractor_profile", "orbgpu_extractor_stage_times",
     "orbgpu_extractor_tables", "orbgpu_extractor_max_keypoints", "orbgpu_extract", "orbgpu_extract_batch",
     "orbgpu_extract_batch_device", "orbgpu_pyramid_level", "orbgpu_pyramid_level_device",
     "orbgpu_debug_level_candidates", "orbgpu_debug_level_selected",
-    "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync",
+    "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync", "orbgpu_matcher_set_grid_geometry",
     "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
     "orbgpu_hamming_bruteforce_device_noalloc",
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
@@ -75,6 +75,7 @@ def load_library():
         L.orbgpu_extractor_destroy.restype = None
         L.orbgpu_extractor_set_stream.argtypes = [vp, vp]
         L.orbgpu_extractor_sync.argtypes = [vp]
+        L.orbgpu_extractor_status.argtypes = [vp, C.POINTER(i32)]
         L.orbgpu_extractor_profile.argtypes = [vp, i32]
         L.orbgpu_extractor_stage_times.argtypes = [vp, vp, C.POINTER(i32)]
         L.orbgpu_extractor_tables.argtypes = [vp, C.POINTER(i32), vp, vp, vp, vp, vp]
@@ -92,6 +93,7 @@ def load_library():
         L.orbgpu_matcher_destroy.restype = None
         L.orbgpu_matcher_set_stream.argtypes = [vp, vp]
         L.orbgpu_matcher_sync.argtypes = [vp]
+        L.orbgpu_matcher_set_grid_geometry.argtypes = [vp, vp]
         L.orbgpu_descriptor_distance.argtypes = [vp, vp]
         L.orbgpu_hamming_bruteforce.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
         L.orbgpu_hamming_bruteforce_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
@@ -218,6 +220,12 @@ class ORBextractor:
     def sync(self):
         _check(self._lib.orbgpu_extractor_sync(self._h), "orbgpu_extractor_sync")
 
+    def status(self):
+        """Overflow flags of the last extract call (bit 0: quadtree node storage, bit 1: keypoints beyond capacity)."""
+        f = C.c_int32()
+        _check(self._lib.orbgpu_extractor_status(self._h, C.byref(f)), "orbgpu_extractor_status")
+        return f.value
+
     def profile(self, enable=True):
         _check(self._lib.orbgpu_extractor_profile(self._h, int(enable)), "orbgpu_extractor_profile")
 
@@ -331,6 +339,11 @@ class ORBmatcher:
 
     def sync(self):
         _check(self._lib.orbgpu_matcher_sync(self._h), "orbgpu_matcher_sync")
+
+    def set_grid_geometry(self, geom6):
+        """Grid geometry of the next windowed search only: (build origin x, y, query origin x, y, 1/cell w, 1/cell h)."""
+        g = None if geom6 is None else np.ascontiguousarray(geom6, np.float32)
+        _check(self._lib.orbgpu_matcher_set_grid_geometry(self._h, _p(g)), "orbgpu_matcher_set_grid_geometry")
 
     @staticmethod
     def DescriptorDistance(a, b):

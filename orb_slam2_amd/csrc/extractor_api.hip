@@ -314,14 +314,25 @@ static int ensure_buffers(orbgpu_extractor *e, const Geom &G, int batch, int img
 // Select the geometry for w x h (recomputing tables when the size changes).
 static void drop_graph(orbgpu_extractor *e);
 
+static int set_geometry_unchecked(orbgpu_extractor *e, int w, int h);
+
 static int set_geometry(orbgpu_extractor *e, int w, int h)
 {
     if (w == e->geom_w && h == e->geom_h) return ORBGPU_OK;
-    drop_graph(e);  // the captured launches name the old geometry's tables and buffers
     if (w > e->p.max_width || h > e->p.max_height) {
         set_error("image %dx%d exceeds the handle's max %dx%d", w, h, e->p.max_width, e->p.max_height);
         return ORBGPU_E_INVALID;
     }
+    drop_graph(e);  // the captured launches name the old geometry's tables and buffers
+    // Buffers may be reallocated and tables overwritten before the new geometry is complete: until it is, the handle
+    // has no geometry, so that a failure here makes the next call start over instead of launching on a mixture.
+    e->geom_w = e->geom_h = 0;
+    e->last_nimg = 0;  // the pyramid of the last call is gone with the old buffers
+    return set_geometry_unchecked(e, w, h);
+}
+
+static int set_geometry_unchecked(orbgpu_extractor *e, int w, int h)
+{
     Geom G;
     std::vector<XTab> xt;
     std::vector<YTab> yt;
@@ -470,6 +481,15 @@ int orbgpu_extractor_sync(orbgpu_extractor *e)
     return ORBGPU_OK;
 }
 
+int orbgpu_extractor_status(orbgpu_extractor *e, int32_t *flags)
+{
+    if (!e || !flags) return ORBGPU_E_INVALID;
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    ORBGPU_HIP_CHECK(hipMemcpy(flags, e->status.p, 4, hipMemcpyDeviceToHost));
+    return ORBGPU_OK;
+}
+
 int orbgpu_extractor_profile(orbgpu_extractor *e, int32_t enable)
 {
     if (!e) return ORBGPU_E_INVALID;
@@ -581,6 +601,8 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
         if (e->prof_used < kProfSets) e->prof_used++;
     }
 #define STAGE_MARK(i) do { if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[i], st)); } while (0)
+    // the status word describes this call alone (a captured sequence clears it on every replay as well)
+    ORBGPU_HIP_CHECK(hipMemsetAsync(e->status.p, 0, 4, st));
     STAGE_MARK(0);
     if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, (uint8_t *)e->pyr.p, G, (const XTab *)e->xtab.p,
                              (const YTab *)e->ytab.p)))
@@ -620,7 +642,7 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
 int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h,
                          int32_t stride, orbgpu_keypoint *kps, uint8_t *desc, int32_t capacity, int32_t *counts)
 {
-    if (!e || !imgs || !kps || !desc || !counts || nimg < 1 || capacity < 0) {
+    if (!e || !imgs || !kps || !desc || !counts || nimg < 1 || capacity < 0 || stride < w) {
         set_error("orbgpu_extract_batch: invalid argument");
         return ORBGPU_E_INVALID;
     }
@@ -696,7 +718,6 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
     ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
     if (*h_status) {
         set_error("internal capacity exceeded (status %d)", *h_status);
-        (void)hipMemsetAsync(e->status.p, 0, 4, st);
         return ORBGPU_E_CAPACITY;
     }
     for (int f = 0; f < nimg; f++) {

@@ -30,7 +30,11 @@ struct MatchArgs {
     const float *uright2;
     const int32_t *n2;
     int32_t t_cap;
-    float minX, minY, maxX, maxY;
+    // 64x48 grid geometry: the train keypoints are binned with origin (gminX, gminY), the query cell ranges are
+    // computed with origin (qminX, qminY), both with the inverse cell sizes invW / invH.  A Frame uses one origin
+    // (src/Frame.cc:397-500); a KeyFrame keeps its Frame's grid and inverse cell sizes but queries with its own
+    // integer-truncated bounds (include/KeyFrame.h:185, src/KeyFrame.cc:585-624).
+    float gminX, gminY, qminX, qminY, invW, invH;
     const uint8_t *occupied;
     int32_t *assign;   // [pair][t_cap]
     int32_t *qmatch;   // [pair][q_cap] or null

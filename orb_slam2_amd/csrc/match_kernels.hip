@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_stereo(StereoArgs A)
     float out_u = -1.0f, out_d = -1.0f;
     int out_sad = -1;
     const orbgpu_keypoint kpL = A.kpsL[iL];
-    const int levelL = kpL.octave;
+    const int levelL = min(max(kpL.octave, 0), A.nlevels - 1);  // the host entry point rejects octaves outside the pyramid
     const float vL = kpL.y, uL = kpL.x;
     const int row = (int)vL;
     const float maxD = __fdiv_rn(A.bf, A.b);

@@ -53,16 +53,6 @@ struct MBuf {
 
 using namespace orbgpu;
 
-struct orbgpu_matcher {
-    int device = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    MBuf part;     // brute-force partial results
-    MBuf scratch;  // window matcher scratch
-    MBuf stats;    // resolver statistics of the last window call
-    int stats_pairs = 0;
-    MBuf stage[12];  // staging for the host entry points
-};
-
 // Partial results of the allocation-free brute-force entry point: one fixed array in every
 // GPU's memory for the life of the process.  Host code never uses the array's name as an
 // address: each device's copy is looked up once with hipGetSymbolAddress while that device is
@@ -93,6 +83,39 @@ static int resolve_noalloc_scratch(int device, void **out)
     }
     if (out) *out = g_noalloc_scratch[device];
     return ORBGPU_OK;
+}
+
+struct orbgpu_matcher {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    MBuf part;     // brute-force partial results
+    MBuf scratch;  // window matcher scratch
+    MBuf stats;    // resolver statistics of the last window call
+    int stats_pairs = 0;
+    MBuf stage[12];  // staging for the host entry points
+    bool geom_set = false;  // one-shot grid geometry of the next windowed call (orbgpu_matcher_set_grid_geometry)
+    float geom[6] = {0, 0, 0, 0, 0, 0};
+};
+
+// Matcher contexts (stream + scratch + staging) are recycled: the reference builds an ORBmatcher on the stack at
+// every call site (src/Tracking.cc:738,951,1060 ...), so create / destroy must not cost a stream and a dozen
+// hipMallocs each time.  orbgpu_matcher_destroy parks an idle context here, orbgpu_matcher_create takes one back.
+static std::mutex g_pool_mutex;
+static std::vector<orbgpu_matcher *> g_pool[ORBGPU_NOALLOC_MAX_DEVICES];
+static const size_t kPoolPerDevice = 8;
+
+// The grid geometry of one windowed call: from the bounds, or the caller's one-shot override.
+static void grid_geometry(orbgpu_matcher *m, const float *b4, MatchArgs *A)
+{
+    if (m->geom_set) {
+        A->gminX = m->geom[0]; A->gminY = m->geom[1]; A->qminX = m->geom[2]; A->qminY = m->geom[3];
+        A->invW = m->geom[4]; A->invH = m->geom[5];
+        m->geom_set = false;
+    } else {  // src/Frame.cc:101-102
+        A->gminX = A->qminX = b4[0]; A->gminY = A->qminY = b4[1];
+        A->invW = (float)ORBGPU_GRID_COLS / (b4[2] - b4[0]);
+        A->invH = (float)ORBGPU_GRID_ROWS / (b4[3] - b4[1]);
+    }
 }
 
 static void choose_split(int nq, int nt, int *nsplit, int *tchunk)
@@ -128,6 +151,14 @@ int orbgpu_matcher_create(int32_t device, orbgpu_matcher **out)
         set_error("device %d out of range (%d devices)", device, ndev);
         return ORBGPU_E_INVALID;
     }
+    if (device < ORBGPU_NOALLOC_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (!g_pool[device].empty()) {
+            *out = g_pool[device].back();
+            g_pool[device].pop_back();
+            return ORBGPU_OK;
+        }
+    }
     orbgpu_matcher *m = new (std::nothrow) orbgpu_matcher();
     if (!m) return ORBGPU_E_NOMEM;
     m->device = device;
@@ -151,6 +182,16 @@ void orbgpu_matcher_destroy(orbgpu_matcher *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->own_stream && m->device < ORBGPU_NOALLOC_MAX_DEVICES) {
+        m->stream = m->own_stream;  // a caller's stream does not outlive its use of the handle
+        m->geom_set = false;
+        m->stats_pairs = 0;
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (g_pool[m->device].size() < kPoolPerDevice) {
+            g_pool[m->device].push_back(m);
+            return;
+        }
+    }
     m->part.release();
     m->scratch.release();
     m->stats.release();
@@ -163,6 +204,20 @@ int orbgpu_matcher_set_stream(orbgpu_matcher *m, void *hip_stream)
 {
     if (!m) return ORBGPU_E_INVALID;
     m->stream = hip_stream ? (hipStream_t)hip_stream : m->own_stream;
+    return ORBGPU_OK;
+}
+
+int orbgpu_matcher_set_grid_geometry(orbgpu_matcher *m, const float *geom6)
+{
+    if (!m) return ORBGPU_E_INVALID;
+    m->geom_set = false;
+    if (!geom6) return ORBGPU_OK;
+    if (!(geom6[4] > 0.0f) || !(geom6[5] > 0.0f)) {
+        set_error("orbgpu_matcher_set_grid_geometry: the inverse cell sizes must be positive");
+        return ORBGPU_E_INVALID;
+    }
+    memcpy(m->geom, geom6, sizeof(m->geom));
+    m->geom_set = true;
     return ORBGPU_OK;
 }
 
@@ -274,7 +329,7 @@ static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orb
     A.mode = mode;
     A.q = d_q; A.qdesc = d_qdesc; A.nq = d_nq; A.q_cap = q_cap;
     A.kps2 = d_kps2; A.desc2 = d_desc2; A.uright2 = d_uright2; A.n2 = d_n2; A.t_cap = t_cap;
-    A.minX = b4[0]; A.minY = b4[1]; A.maxX = b4[2]; A.maxY = b4[3];
+    grid_geometry(m, b4, &A);
     A.occupied = d_occ; A.assign = d_assign; A.qmatch = d_qmatch; A.scratch = (int32_t *)m->scratch.p;
     A.th_dist = th_dist; A.nnratio = nnratio; A.check_orientation = ori; A.nmatches = d_nmatches;
     A.seg_start = d_seg_start; A.seg_index = d_seg_index;
@@ -500,7 +555,7 @@ int orbgpu_assign_features_to_grid(orbgpu_matcher *m, const orbgpu_keypoint *kps
     A.nq = (const int32_t *)m->stage[8].p; A.q_cap = 1;
     A.kps2 = (const orbgpu_keypoint *)m->stage[2].p; A.desc2 = (const uint8_t *)m->stage[3].p;  // descriptors are carried along, unused here
     A.n2 = (const int32_t *)m->stage[8].p + 1; A.t_cap = tc;
-    A.minX = bounds4[0]; A.minY = bounds4[1]; A.maxX = bounds4[2]; A.maxY = bounds4[3];
+    grid_geometry(m, bounds4, &A);
     A.scratch = (int32_t *)m->scratch.p;
     if ((rc = launch_grid_only(st, A))) return rc;
     // scratch layout of one pair (match_scratch_ints): candidates [kTopK*q_cap] | cell_start [3080] | grid records [4*t_cap] ...
@@ -682,6 +737,16 @@ int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extrac
             return ORBGPU_E_INVALID;
         }
     }
+    for (int i = 0; i < nL; i++)
+        if (kpsL[i].octave < 0 || kpsL[i].octave >= nlev) {
+            set_error("orbgpu_stereo_match: left keypoint %d has octave %d of %d levels", i, kpsL[i].octave, nlev);
+            return ORBGPU_E_INVALID;
+        }
+    for (int i = 0; i < nR; i++)
+        if (kpsR[i].octave < 0 || kpsR[i].octave >= nlev) {
+            set_error("orbgpu_stereo_match: right keypoint %d has octave %d of %d levels", i, kpsR[i].octave, nlev);
+            return ORBGPU_E_INVALID;
+        }
     // the extractors may run on other streams: make their work visible first
     if ((rc = orbgpu_extractor_sync(left))) return rc;
     if ((rc = orbgpu_extractor_sync(right))) return rc;

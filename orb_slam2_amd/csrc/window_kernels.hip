@@ -97,8 +97,9 @@ struct PairCtx {
 __device__ __forceinline__ PairCtx make_ctx(const MatchArgs &A, int pair)
 {
     PairCtx P;
-    P.nq = A.nq[pair];
-    P.n2 = A.n2[pair];
+    // the counts come from device memory; every buffer of the pair is sized by the capacities
+    P.nq = min(max(A.nq[pair], 0), A.q_cap);
+    P.n2 = min(max(A.n2[pair], 0), A.t_cap);
     P.Q = A.q + (size_t)pair * A.q_cap;
     P.QD = (const uint32_t *)(A.qdesc + (size_t)pair * A.q_cap * 32);
     P.K2 = A.kps2 + (size_t)pair * A.t_cap;
@@ -121,8 +122,8 @@ __device__ __forceinline__ PairCtx make_ctx(const MatchArgs &A, int pair)
     P.sd_cur = P.sd0;
     P.nxt = s;                         s += A.q_cap;
     P.full = s;
-    P.invW = __fdiv_rn((float)ORBGPU_GRID_COLS, __fsub_rn(A.maxX, A.minX));
-    P.invH = __fdiv_rn((float)ORBGPU_GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+    P.invW = A.invW;
+    P.invH = A.invH;
     return P;
 }
 
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
     for (int i = tid; i < kCells; i += nt_) cursor[i] = 0;
     __syncthreads();
     for (int i = tid; i < n2; i += nt_) {
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.minX), P.invW));
-        const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.minY), P.invH));
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.gminX), P.invW));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.gminY), P.invH));
         if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS) atomicAdd(&cs[px * ORBGPU_GRID_ROWS + py], 1);
     }
     __syncthreads();
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
     // the head array, which is free until the resolver runs.
     auto order_and_write = [&](auto *gidx) {
         for (int i = tid; i < n2; i += nt_) {
-            const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.minX), P.invW));
-            const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.minY), P.invH));
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.gminX), P.invW));
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.gminY), P.invH));
             if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS) {
                 const int cidx = px * ORBGPU_GRID_ROWS + py;
                 gidx[cs[cidx] + atomicAdd(&cursor[cidx], 1)] = i;
@@ -301,10 +302,10 @@ __device__ __forceinline__ void scan_window(const MatchArgs &A, const PairCtx &P
     t2.a = t2.b = kNoKey;
     npass = 0;
     int nk = 0;  // valid entries in wk
-    const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
-    const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
-    const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
-    const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
+    const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.qminX), r), P.invW)));
+    const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.qminX), r), P.invW)));
+    const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.qminY), r), P.invH)));
+    const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.qminY), r), P.invH)));
     if (c0 >= ORBGPU_GRID_COLS || c1 < 0 || r0 >= ORBGPU_GRID_ROWS || r1 < 0) return;
     const int ncols = c1 - c0 + 1;
     int s = 0, len = 0;
@@ -573,10 +574,10 @@ __global__ __launch_bounds__(256) void k_window_topk(MatchArgs A)
     } else {
         // window of this half's query (Frame::GetFeaturesInArea, src/Frame.cc:402-420)
         const float r = q.r;
-        const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
-        const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
-        const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
-        const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
+        const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.qminX), r), P.invW)));
+        const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.qminX), r), P.invW)));
+        const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.qminY), r), P.invH)));
+        const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.qminY), r), P.invH)));
         const bool live = inq && (q.flags & 1) && !(c0 >= ORBGPU_GRID_COLS || c1 < 0 || r0 >= ORBGPU_GRID_ROWS || r1 < 0);
         const int ncols = live ? c1 - c0 + 1 : 0;
         if (__ballot(ncols > 32) == 0ull) {
@@ -623,10 +624,10 @@ __device__ __forceinline__ void lanes_query(const MatchArgs &A, const PairCtx &P
     int npass = 0;
     // window of the query (Frame::GetFeaturesInArea, src/Frame.cc:402-420)
     const float r = q.r;
-    const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
-    const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.minX), r), P.invW)));
-    const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
-    const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.minY), r), P.invH)));
+    const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, A.qminX), r), P.invW)));
+    const int c1 = min(ORBGPU_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, A.qminX), r), P.invW)));
+    const int r0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, A.qminY), r), P.invH)));
+    const int r1 = min(ORBGPU_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, A.qminY), r), P.invH)));
     const bool live = (q.flags & 1) && !(c0 >= ORBGPU_GRID_COLS || c1 < 0 || r0 >= ORBGPU_GRID_ROWS || r1 < 0);
     const bool check = (q.minLevel > 0) || (q.maxLevel >= 0);
     uint32_t qd[8];
@@ -962,8 +963,9 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A, int lds_st
                 selc[i] = -1;  // vMatches12[idx1] = -1 (:856); train features are not exclusive in these matchers
                 atomicSub(&sh_changed, 1);
             } else {
-                // every entry of a losing bin clears its train keypoint and decrements (:1507-1517)
-                assign[s] = -1;
+                // every entry of a losing bin clears its train keypoint and decrements (:1507-1517); -2 tells the
+                // caller that the reference has set this keypoint's map point to NULL, -1 that it never touched it
+                assign[s] = (mode == 1 || mode == 2) ? -2 : -1;
                 atomicSub(&sh_changed, 1);
             }
         }
@@ -987,12 +989,12 @@ __global__ __launch_bounds__(256) void k_shift_queries(const orbgpu_keypoint *__
                                                        float minY, float maxX, float maxY, orbgpu_wquery *__restrict__ q)
 {
     const int pair = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n[pair]) return;
+    if (i >= min(n[pair], capacity)) return;
     const orbgpu_keypoint kp = kps[(size_t)pair * capacity + i];
     orbgpu_wquery w;
     w.u = __fadd_rn(kp.x, du);
     w.v = __fadd_rn(kp.y, dv);
-    w.r = __fmul_rn(th, sc.s[kp.octave]);
+    w.r = __fmul_rn(th, sc.s[min(max(kp.octave, 0), ORBGPU_MAX_LEVELS - 1)]);  // the octave is caller data
     w.minLevel = kp.octave - 1;
     w.maxLevel = kp.octave + 1;
     w.angle = kp.angle;

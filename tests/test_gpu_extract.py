@@ -353,3 +353,36 @@ def test_randomized_sweep(oracle):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     assert fz.main(["--cases", "120", "--seconds", "100", "--seed", "7"]) == 0
+
+
+def test_device_call_overflow_is_reported_and_does_not_stick(oracle):
+    """orbgpu_extract_batch_device with a capacity below the keypoint count truncates and raises status bit 1; the
+    flags describe that call alone: a following host-pointer call on the same handle succeeds."""
+    from tests.hiputil import Hip
+    from orb_slam2_amd import api
+    img = synth.sequence(640, 480, 1, seed=1)[0]
+    ex = _mk(640, 480, 1000)
+    k_ref, d_ref = ex(img)
+    assert len(k_ref) > 900 and ex.status() == 0
+    hip = Hip()
+    try:
+        cap = 100
+        d_img = hip.upload(img)
+        d_k = hip.alloc(cap * 28); d_d = hip.alloc(cap * 32); d_c = hip.alloc(4)
+        ex.extract_batch_device(d_img.value, 1, 640, 480, 640, 640 * 480, d_k.value, d_d.value, cap, d_c.value)
+        assert ex.status() == 2
+        assert hip.download(d_c, 1, np.int32)[0] == cap
+        k_dev = hip.download(d_k, cap, api.KEYPOINT_DTYPE)
+        assert np.array_equal(k_dev, k_ref[:cap])
+        k2, d2 = ex(img)  # the host path on the same handle: no stale flag
+        assert np.array_equal(k2, k_ref) and np.array_equal(d2, d_ref) and ex.status() == 0
+        # replayed graph after an overflowing device call as well
+        ex.extract_batch_device(d_img.value, 1, 640, 480, 640, 640 * 480, d_k.value, d_d.value, cap, d_c.value)
+        k3, _ = ex(img)
+        assert np.array_equal(k3, k_ref)
+    finally:
+        hip.free()
+    kps = np.zeros(ex.max_keypoints, api.KEYPOINT_DTYPE); desc = np.zeros((ex.max_keypoints, 32), np.uint8)
+    n = api.C.c_int32()
+    rc = ex._lib.orbgpu_extract(ex._h, api._p(img), 640, 480, 600, api._p(kps), api._p(desc), ex.max_keypoints, api.C.byref(n))
+    assert rc == -1  # ORBGPU_E_INVALID: row pitch below the width

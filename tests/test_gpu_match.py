@@ -418,3 +418,74 @@ def test_batch_device_many_pairs(oracle, frames, mode, th, tcap):
         assert NM[p] == rn, "pair %d" % p
         assert np.array_equal(A[p, :N2[p]], rassign), "pair %d" % p
     assert NM.sum() > 5000
+
+
+@pytest.mark.parametrize("which", ["in_area", "projection"])
+def test_keyframe_grid_geometry(matcher, oracle, frames, which):
+    """A KeyFrame keeps its Frame's grid (binned with the Frame's float bounds) but computes query cell ranges from
+    its own int-truncated bounds (include/KeyFrame.h:185, src/KeyFrame.cc:585-624): build origin, query origin and
+    inverse cell sizes are given explicitly, for one call; the next call is back to its bounds."""
+    from orb_slam2_amd import api
+    (k1, d1), (k2, d2) = frames[0], frames[1]
+    sc = oracle.tables(oracle.make_params(1000))["scale"]
+    fb = np.array([-7.62, -5.31, 652.4, 488.7], np.float32)           # undistorted image bounds of a Frame
+    geom = np.array([fb[0], fb[1], np.trunc(fb[0]), np.trunc(fb[1]),  # the KeyFrame's truncated origin for queries
+                     np.float32(64) / (fb[2] - fb[0]), np.float32(48) / (fb[3] - fb[1])], np.float32)
+    ib = np.trunc(fb).astype(np.float32)
+    q = api.shift_queries(k1, -2.0, -1.0, 6.0, sc, ib)
+    q["minLevel"] = k1["octave"] - 1; q["maxLevel"] = k1["octave"]
+    q = q.astype(api.WQUERY_DTYPE)
+    for use_geom in (True, False, True):
+        if use_geom:
+            matcher.set_grid_geometry(geom)
+        if which == "in_area":
+            n, out = matcher.SearchInArea(q, d1, k2, d2, ib, th_dist=100)
+            rn, rout = oracle.search_in_area(q.view(oracle.WQUERY_DTYPE), d1, k2.view(oracle.KEYPOINT_DTYPE), d2, ib,
+                                             th_dist=100, geom6=geom if use_geom else None)
+        else:
+            n, out = matcher.SearchByProjection(api.MODE_KEYFRAME, q, d1, k2, d2, ib, th_dist=50)
+            rn, rout = oracle.search_by_projection(2, q.view(oracle.WQUERY_DTYPE), d1, k2.view(oracle.KEYPOINT_DTYPE), d2, ib,
+                                                   th_dist=50, nnratio=0.9, checkOri=True, geom6=geom if use_geom else None)
+        assert n == rn and np.array_equal(out, rout) and n > 100, (which, use_geom)
+    with pytest.raises(api.OrbGpuError):
+        matcher.set_grid_geometry(np.array([0, 0, 0, 0, 0, 0.1], np.float32))
+    matcher.set_grid_geometry(None)
+
+
+def test_rotation_filter_marks_cleared_keypoints(matcher, oracle, frames):
+    """assign = -2 where the rotation-consistency filter removed a match (the reference sets that keypoint's map point
+    to NULL), -1 where the search never touched the keypoint."""
+    from orb_slam2_amd import api
+    (k1, d1), (k2, d2) = frames[0], frames[1]
+    sc = oracle.tables(oracle.make_params(1000))["scale"]
+    q = api.shift_queries(k1, -2.0, -1.0, 25.0, sc, _bounds())
+    q["angle"] = (q["angle"] + np.where(np.arange(len(q)) % 7 == 0, 95.0, 0.0)).astype(np.float32) % 360.0
+    n, assign = matcher.SearchByProjection(api.MODE_LAST_FRAME, q, d1, k2, d2, _bounds())
+    rn, rassign = oracle.search_by_projection(1, q.view(oracle.WQUERY_DTYPE), d1, k2.view(oracle.KEYPOINT_DTYPE), d2, _bounds(),
+                                              th_dist=100, nnratio=0.9, checkOri=True)
+    assert n == rn and np.array_equal(assign, rassign)
+    assert (assign == -2).sum() > 20 and (assign == -1).sum() > 0 and (assign >= 0).sum() == n
+
+
+def test_matcher_contexts_are_recycled():
+    """ORBmatcher is a stack object at every call site of the reference (src/Tracking.cc:738,951,1060): creating one
+    must not cost a stream and fresh device buffers each time."""
+    import time
+    from orb_slam2_amd import api
+    Q = synth.descriptors(300, 1); T = synth.descriptors(500, 2)
+    m = api.ORBmatcher(0.9, True)
+    ref = m.BruteForce(Q, T)
+    h0 = m._h.value
+    m.close()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        m = api.ORBmatcher(0.7, False)
+        assert m._h.value == h0  # the parked context comes back
+        m.close()
+    per_pair = (time.perf_counter() - t0) / 200
+    assert per_pair < 200e-6, per_pair
+    a = api.ORBmatcher(); b = api.ORBmatcher()  # two live matchers never share a context
+    assert a._h.value != b._h.value
+    for got in (a.BruteForce(Q, T), b.BruteForce(Q, T)):
+        assert all(np.array_equal(x, y) for x, y in zip(got, ref))
+    a.close(); b.close()

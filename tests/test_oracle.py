@@ -448,7 +448,7 @@ def test_search_by_projection_last_frame_against_python(oracle, two_frames):
     for bi_, h in enumerate(hist):
         if bi_ not in keep:
             for t in h:
-                ref[t] = -1; cnt -= 1
+                ref[t] = -2; cnt -= 1  # cleared by the rotation filter (NULL in the reference), not merely untouched
     assert n == cnt and np.array_equal(assign, ref) and cnt > 100
 
 
