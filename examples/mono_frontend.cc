@@ -7,6 +7,8 @@
 // (src/Frame.cc:503-510) on the first frame through ORB_SLAM2::ORBVocabulary.
 //
 // Build: g++ -std=c++14 -Iinclude examples/mono_frontend.cc -Lorb_slam2_amd -lorbgpu -Wl,-rpath,$PWD/orb_slam2_amd
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -62,5 +64,32 @@ int main(int argc, char **argv)
         std::printf("words %u bow %zu sum %.17g nodes %zu features %zu checksum %ld\n", voc.size(), bow.size(), total, fv.size(), nfeat,
                     fsum);
     }
+    // Per-frame latency of the two calls as Tracking makes them (src/Tracking.cc:160-168, 738-748): operator() on a
+    // resident extractor, and an ORBmatcher built on the stack for one search.  Median of 50 after 5 warm-ups, with
+    // std::chrono::steady_clock around each call like the reference's drivers (Examples/Monocular/mono_tum.cc:79-96).
+    typedef std::chrono::steady_clock clk;
+    std::vector<double> te, tm, tc;
+    for (int it = 0; it < 55; it++) {
+        const clk::time_point t0 = clk::now();
+        extractor(im[it & 1], nomask, keys[it & 1], desc[it & 1]);
+        const clk::time_point t1 = clk::now();
+        int nm;
+        clk::time_point t2;
+        {
+            ORB_SLAM2::ORBmatcher onStack(0.9f, true);
+            t2 = clk::now();
+            for (size_t i = 0; i < keys[0].size(); i++) prev[i] = keys[0][i].pt;
+            nm = onStack.SearchForInitialization(keys[0], desc[0], keys[1], desc[1], bounds, prev, matches12, 100);
+        }
+        const clk::time_point t3 = clk::now();
+        if (nm != n) { std::fprintf(stderr, "match count changed between calls: %d vs %d\n", nm, n); return 1; }
+        if (it >= 5) {
+            te.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+            tc.push_back(std::chrono::duration<double, std::micro>(t2 - t1).count());
+            tm.push_back(std::chrono::duration<double, std::milli>(t3 - t1).count());
+        }
+    }
+    std::sort(te.begin(), te.end()); std::sort(tm.begin(), tm.end()); std::sort(tc.begin(), tc.end());
+    std::printf("latency extract_ms %.4f stack_matcher_ms %.4f matcher_ctor_us %.2f\n", te[te.size() / 2], tm[tm.size() / 2], tc[tc.size() / 2]);
     return 0;
 }

@@ -3,6 +3,8 @@
  * (reference: /root/reference/src/ORB_SLAM2/include/ORBextractor.h:44-113) on
  * top of the C ABI in orbgpu.h.  Same constructor, operator(), getters and the
  * public mvImagePyramid member, so Frame.cc / Tracking.cc compile unchanged.
+ * operator() moves one image to the device and the keypoints and descriptors
+ * back; pyramid levels cross the bus only if mvImagePyramid[level] is read.
  *
  * With OpenCV available define ORBGPU_WITH_OPENCV before including this file:
  * the class then takes cv::InputArray / cv::OutputArray / cv::KeyPoint exactly
@@ -56,6 +58,40 @@ typedef Mat &OutputArray;
 
 namespace ORB_SLAM2 {
 
+// mvImagePyramid of the reference is a std::vector<cv::Mat> that every extraction fills
+// (include/ORBextractor.h:85).  Its only readers are `mvImagePyramid[level]` expressions in
+// Frame::ComputeStereoMatches (src/Frame.cc:607,697,709,714) -- and a program whose stereo matching runs
+// on the GPU (ORBmatcher::ComputeStereoMatches) never reads it.  This stand-in keeps that expression
+// working but copies a level from the device only when it is first asked for after an extraction.
+class ImagePyramidMirror {
+public:
+    size_t size() const { return levels_.size(); }
+    bool empty() const { return levels_.empty(); }
+    orbcv::Mat &operator[](size_t level) { fetch(level); return levels_[level]; }
+    const orbcv::Mat &operator[](size_t level) const { fetch(level); return levels_[level]; }
+    orbcv::Mat &at(size_t level) { fetch(level); return levels_.at(level); }
+
+private:
+    friend class ORBextractor;
+    void bind(orbgpu_extractor *h, int nlevels) { handle_ = h; levels_.resize((size_t)nlevels); fresh_.assign((size_t)nlevels, 0); }
+    void invalidate() { fresh_.assign(fresh_.size(), 0); }
+    void fetch(size_t l) const
+    {
+        if (!handle_ || l >= levels_.size() || fresh_[l]) return;
+        int32_t lw = 0, lh = 0;
+        if (orbgpu_pyramid_level(handle_, 0, (int32_t)l, 0, 0, nullptr, 0, &lw, &lh) != ORBGPU_OK) return;
+#ifdef ORBGPU_WITH_OPENCV
+        levels_[l].create(lh, lw, CV_8U);
+#else
+        levels_[l].create(lh, lw);
+#endif
+        if (orbgpu_pyramid_level(handle_, 0, (int32_t)l, 0, 0, levels_[l].data, (int)levels_[l].step, &lw, &lh) == ORBGPU_OK) fresh_[l] = 1;
+    }
+    orbgpu_extractor *handle_ = nullptr;
+    mutable std::vector<orbcv::Mat> levels_;
+    mutable std::vector<char> fresh_;
+};
+
 class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
@@ -79,7 +115,7 @@ public:
         orbgpu_extractor_tables(handle_, &n, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
                                 mvInvLevelSigma2.data(), mnFeaturesPerLevel.data());
         orbgpu_extractor_max_keypoints(handle_, &max_kp_);
-        mvImagePyramid.resize(nlevels);
+        mvImagePyramid.bind(handle_, nlevels);
     }
     ~ORBextractor() { orbgpu_extractor_destroy(handle_); }
     ORBextractor(const ORBextractor &) = delete;
@@ -117,19 +153,7 @@ public:
         if (n == 0) descriptors.release();
         else { descriptors.create(n, 32); std::memcpy(descriptors.data, desc_buf_.data(), (size_t)n * 32); }
 #endif
-        // mvImagePyramid is public in the reference and read by Frame::ComputeStereoMatches
-        // (src/Frame.cc:607,697,709,714): mirror every level on the host.
-        for (int l = 0; l < nlevels; l++) {
-            int32_t lw = 0, lh = 0;
-            if (orbgpu_pyramid_level(handle_, 0, l, 0, 0, nullptr, 0, &lw, &lh) != ORBGPU_OK) break;
-#ifdef ORBGPU_WITH_OPENCV
-            mvImagePyramid[l].create(lh, lw, CV_8U);
-            orbgpu_pyramid_level(handle_, 0, l, 0, 0, mvImagePyramid[l].data, (int)mvImagePyramid[l].step, &lw, &lh);
-#else
-            mvImagePyramid[l].create(lh, lw);
-            orbgpu_pyramid_level(handle_, 0, l, 0, 0, mvImagePyramid[l].data, (int)mvImagePyramid[l].step, &lw, &lh);
-#endif
-        }
+        mvImagePyramid.invalidate();  // levels are copied from the device when somebody reads them
     }
 
     // reference: include/ORBextractor.h:63-83
@@ -140,7 +164,7 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    std::vector<orbcv::Mat> mvImagePyramid;  // include/ORBextractor.h:85
+    ImagePyramidMirror mvImagePyramid;  // include/ORBextractor.h:85; read as mvImagePyramid[level]
 
     orbgpu_extractor *Handle() { return handle_; }  // for ORBmatcher::ComputeStereoMatches
     const std::string &LastError() const { return err_; }

@@ -4,18 +4,27 @@
  * /root/reference/src/ORB_SLAM2/include/ORBmatcher.h:41-103) on top of the C
  * ABI in orbgpu.h.
  *
- * The reference's search methods take Frame / KeyFrame / MapPoint objects; the
- * pose projection that turns a map point into an image window is host glue
- * outside the descriptor path.  The methods here therefore take the arrays
- * those objects hold (keypoints, descriptors, mvuRight, "has a map point"
- * flags) plus one window query per map point; the Frame-based overloads become
- * few-line adapters that keep their pose arithmetic and fill those arrays.
+ * Two layers.  (1) The eleven search methods with the reference's own
+ * signatures (include/ORBmatcher.h:48-83 of the reference), as member templates
+ * over the caller's Frame / KeyFrame / MapPoint types: declared here, defined in
+ * ORBmatcherFrames.h, which this header includes.  (2) Array forms of the same
+ * searches (keypoints, descriptors, mvuRight, "has a map point" flags plus one
+ * window query per map point) for callers that hold arrays; layer (1) is built
+ * on them.
+ *
+ * An ORBmatcher is a value: the reference creates one on the stack at every call
+ * site (src/Tracking.cc:738,951,1060,1381,1568; src/LocalMapping.cc:215,483;
+ * src/LoopClosing.cc:241,325,377,591).  Construction takes a recycled GPU context
+ * from the library (no stream creation, no allocation after the first few), and
+ * copies get a context of their own.
  */
 #ifndef ORBGPU_ORBMATCHER_H
 #define ORBGPU_ORBMATCHER_H
 
 #include <map>
+#include <set>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -27,13 +36,51 @@ namespace ORB_SLAM2 {
 class ORBmatcher {
 public:
     // reference: include/ORBmatcher.h:41
-    ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device = 0) : mfNNratio(nnratio), mbCheckOrientation(checkOri)
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device = 0)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device)
     {
         if (orbgpu_matcher_create(device, &handle_) != ORBGPU_OK) { handle_ = nullptr; err_ = orbgpu_last_error(); }
     }
     ~ORBmatcher() { orbgpu_matcher_destroy(handle_); }
-    ORBmatcher(const ORBmatcher &) = delete;
-    ORBmatcher &operator=(const ORBmatcher &) = delete;
+    ORBmatcher(const ORBmatcher &o) : mfNNratio(o.mfNNratio), mbCheckOrientation(o.mbCheckOrientation), device_(o.device_)
+    {
+        if (orbgpu_matcher_create(device_, &handle_) != ORBGPU_OK) { handle_ = nullptr; err_ = orbgpu_last_error(); }
+    }
+    ORBmatcher &operator=(const ORBmatcher &o)  // the context stays, the settings are copied
+    {
+        mfNNratio = o.mfNNratio;
+        mbCheckOrientation = o.mbCheckOrientation;
+        return *this;
+    }
+
+    // ---- the reference's search methods (include/ORBmatcher.h:48-83), defined in ORBmatcherFrames.h ----------
+    template <class FrameT, class MapPointT>
+    int SearchByProjection(FrameT &F, const std::vector<MapPointT *> &vpMapPoints, const float th = 3);
+    template <class FrameT>
+    int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool bMono);
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int SearchByProjection(FrameT &CurrentFrame, KeyFrameT *pKF, const std::set<MapPointT *> &sAlreadyFound, const float th,
+                           const int ORBdist);
+    template <class KeyFrameT, class MatT, class MapPointT>
+    int SearchByProjection(KeyFrameT *pKF, MatT Scw, const std::vector<MapPointT *> &vpPoints, std::vector<MapPointT *> &vpMatched, int th);
+    template <class KeyFrameT, class FrameT, class MapPointT>
+    typename std::enable_if<!std::is_pointer<FrameT>::value, int>::type
+    SearchByBoW(KeyFrameT *pKF, FrameT &F, std::vector<MapPointT *> &vpMapPointMatches);
+    template <class KeyFrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPointT *> &vpMatches12);
+    template <class FrameT, class PointT>
+    int SearchForInitialization(FrameT &F1, FrameT &F2, std::vector<PointT> &vbPrevMatched, std::vector<int> &vnMatches12,
+                                int windowSize = 10);
+    template <class KeyFrameT, class MatT>
+    int SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT *pKF2, MatT F12, std::vector<std::pair<size_t, size_t> > &vMatchedPairs,
+                               const bool bOnlyStereo);
+    template <class KeyFrameT, class MapPointT, class MatT>
+    int SearchBySim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPointT *> &vpMatches12, const float &s12, const MatT &R12,
+                     const MatT &t12, const float th);
+    template <class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints, const float th = 3.0);
+    template <class KeyFrameT, class MatT, class MapPointT>
+    int Fuse(KeyFrameT *pKF, MatT Scw, const std::vector<MapPointT *> &vpPoints, float th, std::vector<MapPointT *> &vpReplacePoint);
 
     // reference: include/ORBmatcher.h:44, src/ORBmatcher.cc:1710-1727 (rows of 32 bytes)
     static int DescriptorDistance(const orbcv::Mat &a, const orbcv::Mat &b) { return orbgpu_descriptor_distance(a.data, b.data); }
@@ -294,19 +341,23 @@ public:
         return nvalid;
     }
 
-    // reference: include/ORBmatcher.h:92, src/ORBmatcher.cc:1661-1704 (on bin sizes)
-    static void ComputeThreeMaxima(const int *histoSizes, const int L, int &ind1, int &ind2, int &ind3)
+    // reference: include/ORBmatcher.h:98, src/ORBmatcher.cc:1661-1704: the three fullest bins of the rotation histogram,
+    // the second and third only if they hold at least a tenth of the fullest.  Among equally full bins the lower index
+    // ranks first (a bin must be strictly fuller to displace one).
+    static void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3)
     {
-        int max1 = 0, max2 = 0, max3 = 0;
-        ind1 = ind2 = ind3 = -1;
+        int top[3] = {0, 0, 0}, at[3] = {-1, -1, -1};
         for (int i = 0; i < L; i++) {
-            const int s = histoSizes[i];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
+            const int s = (int)histo[i].size();
+            int rank = 0;
+            while (rank < 3 && s <= top[rank]) rank++;
+            for (int k = 2; k > rank; k--) { top[k] = top[k - 1]; at[k] = at[k - 1]; }
+            if (rank < 3) { top[rank] = s; at[rank] = i; }
         }
-        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        const float floor_ = 0.1f * (float)top[0];
+        if ((float)top[1] < floor_) at[1] = at[2] = -1;
+        else if ((float)top[2] < floor_) at[2] = -1;
+        ind1 = at[0]; ind2 = at[1]; ind3 = at[2];
     }
 
     static const int TH_LOW = ORBGPU_TH_LOW;            // src/ORBmatcher.cc:38
@@ -325,10 +376,13 @@ private:
         if (rc != ORBGPU_OK) err_ = orbgpu_last_error();
         return rc;
     }
+    int device_ = 0;
     orbgpu_matcher *handle_ = nullptr;
     std::string err_;
 };
 
 }  // namespace ORB_SLAM2
+
+#include "ORBmatcherFrames.h"
 
 #endif
