@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the ORB front-end path (extract + windowed match) on MI355X.
 
-One "step" = one batch of B (default 2048) synthetic TUM-like frames (640x480, 1000 features,
-8 levels, scale 1.2, FAST 20/7), already resident in HBM: extract all B frames,
-then SearchByProjection(Cur, Last)-style windowed matching of every frame
-against its predecessor (the predecessor of frame 0 is the last frame of the
-previous step).  Metric: frames/s, whole job (all ranks).
+Default workload (`--workload tum`, the configuration the metric is quoted on): one "step" = one batch of B
+(default 2048) synthetic TUM-like frames (640x480, 1000 features, 8 levels, scale 1.2, FAST 20/7) per GPU, already
+resident in HBM: extract all B frames, then SearchByProjection(Cur, Last)-style windowed matching of every frame
+against its predecessor (the predecessor of frame 0 is the last frame of the previous step).  Metric: frames/s of the
+whole job.  Every rank runs the same per-GPU workload on its own sequence (weak scaling).
 
-Multi-GPU: one process per GPU, every rank runs the same per-GPU workload on its
-own frames (weak scaling); there is no data-path collective, torch.distributed
-is used only for the barrier and the max-over-ranks of the elapsed time.
+`--workload 4k`: 256 frames of 3840x2160 with 8000 features, extraction only, device-resident, the 256 frames sharded
+across the ranks in contiguous chunks (strong scaling).
+
+Multi-GPU: one process per GPU, no data-path collective; torch.distributed (RCCL) only lines the ranks up (barrier)
+and takes the slowest rank's time.  Under torchrun the ranks come from the environment; `--gpus N` without a torchrun
+environment makes this process a launcher that starts N rank processes itself (it never touches the GPU) and prints
+rank 0's line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +34,180 @@ W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 640, 480, 1000, 8, 1.2, 20, 7
 STEP = (2, 1)   # per-frame image motion of the synthetic sequence
 TH_PROJ = 15.0  # Tracking.cc:1060-1066 (monocular window)
 HBM_PEAK_GBS = 8000.0
+KERNEL_OF_STAGE = {"pyramid": "k_pyr_resize", "fast_cells": "k_fast_cells", "octree": "k_octree_batch", "blur": "k_blur",
+                   "describe": "k_describe"}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# ranks
+# ---------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv, extra_env=None, timeout=None):
+    """Start `n` rank processes of `argv` on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun
+    would), wait for all, return (exit code, stdout of rank 0).  The caller must not have initialised the GPU."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, rc = "", 0
+    deadline = None if timeout is None else time.time() + timeout
+    try:
+        out0 = procs[0].communicate(timeout=timeout)[0]
+        for p in procs:
+            p.wait(timeout=None if deadline is None else max(1.0, deadline - time.time()))
+            rc = rc or p.returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc, out0
+
+
+def init_ranks(backend, device=None):
+    """(rank, local_rank, world) from the environment; joins the process group when world > 1."""
+    from orb_slam2_amd.dist import env_world
+    rank, local_rank, world = env_world()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def timed_steps(step, steps, warmup, sync, barrier):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + sync on both sides.  Seconds on this rank."""
+    for _ in range(warmup):
+        step()
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync(); barrier(); sync()
+    return time.perf_counter() - t0
+
+
+def bench_line(metric, unit, value, world, steps, warmup, wall_max, scaling, dtype, data, config, **more):
+    out = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": wall_max / steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+           "dtype": dtype, "data": data, "config": config}
+    out.update(more)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a scalar port of the reference's algorithm) on the GPU box's host cores
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(frames, n_frames=400, n_stereo=60, pool_threads=None, per_thread=100):
+    """Timed like the reference's drivers (Examples/Monocular/mono_tum.cc:79-96: steady clock around the per-frame
+    call, median over the frames) after 5 warm-up frames.
+    (a) one thread: extract + windowed match per frame -- what the reference does for mono / RGB-D (src/Frame.cc:136,212);
+    (b) two threads: left || right extraction (src/Frame.cc:78-81) + ComputeStereoMatches on KITTI-sized pairs;
+    (c) for context, the mono workload frame-parallel on the host cores this job may use."""
+    import threading
+    from oracle import oracle as O
+    from orb_slam2_amd import api, synth
+    O.build()
+    oe = O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
+    sc = O.tables(oe.p)["scale"]
+    bounds = np.array([0, 0, W, H], np.float32)
+
+    def one(ex, prev, f):
+        cur = ex.extract(f)
+        q = api.shift_queries(prev[0], -STEP[0], -STEP[1], TH_PROJ, sc, bounds)
+        O.search_by_projection(1, q.view(O.WQUERY_DTYPE), prev[1], cur[0], cur[1], bounds, th_dist=100, nnratio=0.9, checkOri=True)
+        return cur
+
+    t_start = time.perf_counter()
+    prev = oe.extract(frames[0])
+    per = []
+    for k in range(1, n_frames + 6):
+        t0 = time.perf_counter()
+        prev = one(oe, prev, frames[k % len(frames)])
+        if k > 5:
+            per.append(time.perf_counter() - t0)
+    per = np.asarray(per)
+    res = {"value": 1.0 / float(np.median(per)), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the same sequence after 5 warm-ups, extract + windowed match per frame on one thread, "
+                     "median per-frame time %.2f ms (mean %.2f ms)" % (len(per), np.median(per) * 1e3, per.mean() * 1e3),
+           "cpu_model": cpu_model(), "host_cores_visible": os.cpu_count()}
+
+    # (b) stereo, two threads
+    L, R, _ = synth.stereo_pair(1241, 376, seed=2)
+    exL, exR = O.Extractor(2000, SCALE, NLEVELS, INI_TH, MIN_TH), O.Extractor(2000, SCALE, NLEVELS, INI_TH, MIN_TH)
+    tabs = O.tables(exL.p)
+    per = []
+    for k in range(n_stereo + 3):
+        t0 = time.perf_counter()
+        box = {}
+        th = threading.Thread(target=lambda: box.__setitem__("R", exR.extract(R)))
+        th.start()
+        kL, dL = exL.extract(L)
+        th.join()
+        kR, dR = box["R"]
+        O.stereo_matches(kL, dL, kR, dR, [exL.level(l) for l in range(NLEVELS)], [exR.level(l) for l in range(NLEVELS)],
+                         tabs["scale"], tabs["inv_scale"], 386.1448, 386.1448 / 718.856)
+        if k >= 3:
+            per.append(time.perf_counter() - t0)
+    per = np.asarray(per)
+    res["stereo_2_threads"] = {"value": 1.0 / float(np.median(per)), "unit": "stereo frames/s", "cores": 2,
+                               "sample": "%d KITTI-sized pairs (1241x376, 2000 features per eye): left || right extraction on two "
+                                         "threads + ComputeStereoMatches, median %.2f ms" % (len(per), np.median(per) * 1e3)}
+
+    # (c) all cores this job may use (the box gives one GPU's share of the host: OMP_NUM_THREADS)
+    nth = pool_threads or max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16)))
+    exs = [O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH) for _ in range(nth)]
+
+    def worker(t):
+        p = exs[t].extract(frames[t % len(frames)])
+        for k in range(per_thread):
+            p = one(exs[t], p, frames[(t * per_thread + k + 1) % len(frames)])
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nth)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    res["all_cores"] = {"value": nth * per_thread / dt, "unit": "frames/s", "cores": nth,
+                        "sample": "%d threads x %d frames, frame-parallel, %.1f s" % (nth, per_thread, dt)}
+    res["seconds_total"] = time.perf_counter() - t_start
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# helpers for the roofline block
+# ---------------------------------------------------------------------------------------------------------------
 def level_pixels(w, h):
-    sc, tot, sizes = 1.0, 0, []
+    tot, sizes = 0, []
     f = np.float32(1.0)
-    for l in range(NLEVELS):
+    for _ in range(NLEVELS):
         inv = np.float32(1.0) / f
         lw, lh = int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))
         sizes.append((lw, lh))
@@ -42,64 +216,84 @@ def level_pixels(w, h):
     return tot, sizes
 
 
-def cpu_baseline(frames, n_frames):
-    """Oracle (scalar CPU port) timed on one host core over a bounded sample."""
-    from oracle import oracle as O
-    O.build()
-    oe = O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
-    sc = O.tables(oe.p)["scale"]
-    from orb_slam2_amd import api
-    bounds = np.array([0, 0, W, H], np.float32)
-    prev = oe.extract(frames[0])
-    t0 = time.perf_counter()
-    for k in range(1, n_frames + 1):
-        f = frames[k % len(frames)]
-        cur = oe.extract(f)
-        q = api.shift_queries(prev[0], -STEP[0], -STEP[1], TH_PROJ, sc, bounds)
-        O.search_by_projection(1, q.view(O.WQUERY_DTYPE), prev[1], cur[0], cur[1], bounds, th_dist=100, nnratio=0.9,
-                               checkOri=True)
-        prev = cur
-    dt = time.perf_counter() - t0
-    return n_frames / dt, dt
+def committed_counters(kernel, launch_frames):
+    """HBM traffic and vector-instruction counts of `kernel` from the committed rocprofv3 PMC passes (builder-run on a
+    one-stream schedule with `launch_frames` frames per launch; counters cannot be collected inside a timed run)."""
+    traffic = valu = None
+    src = []
+    for tag in ("r02", "r01"):
+        p = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
+        if traffic is None and os.path.exists(p):
+            try:
+                pm = json.load(open(p))
+                if pm.get("batch") == launch_frames and kernel in pm["kernels"]:
+                    kk = pm["kernels"][kernel]
+                    traffic = (kk["FETCH_SIZE_KB_per_launch"] * kk.get("fetch_corr", 1.0) + kk["WRITE_SIZE_KB_per_launch"]) * 1024
+                    src.append("profiles/%s_pmc_traffic.json" % tag)
+            except Exception:
+                pass
+        p = os.path.join(ROOT, "profiles", "%s_sq_counters.txt" % tag)
+        if valu is None and os.path.exists(p) and launch_frames == 512:
+            for line in open(p):
+                f = line.split()
+                if f and f[0] == kernel:
+                    valu = float(f[2])
+                    src.append("profiles/%s_sq_counters.txt" % tag)
+    return traffic, valu, src
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2048, help="frames per step and GPU")
-    ap.add_argument("--streams", type=int, default=4, help="independent sub-pipelines (HIP streams) the batch is split over")
-    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency probe (profiling runs)")
-    ap.add_argument("--cpu-frames", type=int, default=800, help="frames of the CPU baseline sample (0 = skip)")
-    args = ap.parse_args()
+def measured_issue_peak():
+    """Chip-wide wave-instructions per second from the committed issue-rate microbenchmark (tools/valu_issue.hip):
+    the mean over the packed-integer opcodes the FAST kernel is made of, at 8 waves per SIMD."""
+    p = os.path.join(ROOT, "profiles", "r02_valu_issue.json")
+    if not os.path.exists(p):
+        return None, None
+    try:
+        j = json.load(open(p))
+        ops = ["v_pk_min_i16", "v_pk_max_u16", "v_perm_b32", "v_alignbyte_b32", "v_xor_b32", "v_min_u32"]
+        v = [j["ops"][o]["waves_per_simd_8"]["chip_Gwave_instr_per_s"] for o in ops if o in j["ops"]]
+        return (float(np.mean(v)) * 1e9, "profiles/r02_valu_issue.json") if v else (None, None)
+    except Exception:
+        return None, None
 
-    import torch
-    import torch.distributed as dist
+
+def cpp_latency(frames):
+    """operator() and a stack ORBmatcher through the C++ classes (examples/mono_frontend, a child process)."""
+    exe = os.path.join(ROOT, "examples", "mono_frontend")
+    if not os.path.exists(exe):
+        return None
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".raw", delete=False) as f:
+        f.write(np.array([W, H], np.int32).tobytes())
+        f.write(np.ascontiguousarray(frames[:2]).tobytes())
+        path = f.name
+    try:
+        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=120)
+        for line in r.stdout.splitlines():
+            t = line.split()
+            if t and t[0] == "latency":
+                return {"extract_ms": float(t[2]), "stack_matcher_search_ms": float(t[4]), "matcher_ctor_us": float(t[6]),
+                        "note": "C++ ORBextractor::operator() and an ORBmatcher built on the stack + SearchForInitialization per "
+                                "frame (include/ORBextractor.h, include/ORBmatcher.h), host pointers in and out, median of 50"}
+    except Exception:
+        return None
+    finally:
+        os.unlink(path)
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------
+def run_tum(args, rank, local_rank, world, torch, dev, barrier):
     from orb_slam2_amd import api, synth
-
-    from orb_slam2_amd.dist import env_world, max_over_ranks
-    rank, local_rank, world = env_world()
-    # rehearsal of the multi-rank path on a one-GPU box: ORBGPU_BENCH_REHEARSAL=1 puts every rank on device 0 and
-    # lines the ranks up over gloo (RCCL refuses two ranks on one device); never set in a measured run
-    rehearsal = os.environ.get("ORBGPU_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
+    from orb_slam2_amd.dist import max_over_ranks
     B = args.batch
     frames = synth.sequence(W, H, B, seed=1 + rank, step=STEP, per_frame_density=True)
     d_imgs = torch.from_numpy(frames).to(dev)
 
-    # S independent sub-pipelines (own extractor + matcher handle, own HIP stream), each taking B/S
-    # consecutive frames of the batch: the latency-bound kernels of one overlap the ALU-bound ones of another
+    # S independent sub-pipelines (own extractor + matcher handle, own HIP stream), each taking B/S consecutive
+    # frames of the batch: the latency-bound kernels of one overlap the ALU-bound ones of another
     S = args.streams
     assert B % S == 0, "--batch must be a multiple of --streams"
     Bs = B // S
@@ -153,50 +347,74 @@ def main():
             d_cnt[0:1].copy_(d_cnt[B:B + 1], non_blocking=True)
             ev_carried.record(streams[0])
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+    def sync():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
-    barrier()
-    ex.profile(True)
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    for k in range(1, S):
-        stream.wait_event(ev_matched[k])
-    ev1.record(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
-    stage_ms, ncalls = ex.stage_times()
+    sync()
+    ex.profile(True)  # HIP events between the stages on the stream the kernels are launched on
+    wall = timed_steps(step, args.steps, 0, sync, barrier)
+    stage_ms, _ = ex.stage_times()
     ex.profile(False)
+    wall_max = max_over_ranks(wall, dev if world > 1 else None)
 
     # the same launches of sub-pipeline 0 with nothing else on the chip (after the timed region): in the timed region
-    # the event times include the other sub-pipelines' kernels and the side-stream blur, this pass tells the stages apart
+    # the event intervals include the other sub-pipelines' kernels and the side-stream blur, this pass tells the stages apart
     ex.profile(2)  # blur kept on the main stream: every stage alone
     for _ in range(3):
         with torch.cuda.stream(stream):
             ex.extract_batch_device(d_imgs[0].data_ptr(), Bs, W, H, W, W * H, d_kps[1].data_ptr(), d_desc[1].data_ptr(), cap,
                                     d_cnt[1:].data_ptr())
-    torch.cuda.synchronize(dev)
+    sync()
     iso_ms, _ = ex.stage_times()
     ex.profile(False)
 
-    wall_max = max_over_ranks(wall, None if rehearsal else dev)
-
+    if rank != 0:
+        return None
     wstats = [mt.window_stats(p) for p in range(0, Bs, max(1, Bs // 8))]
     kp_mean = float(d_cnt[1:].float().mean().item())
     nm_mean = float(d_nm.float().mean().item())
+    P, _ = level_pixels(W, H)
+    names = ["pyramid", "fast_cells", "octree", "blur", "describe"]
+    alg = {"pyramid": W * H + P, "fast_cells": P, "octree": 0, "blur": 2 * P, "describe": int(kp_mean * 60)}
+    # dominant kernel = the single-launch stage with the longest isolated time (the pyramid stage is a chain of launches)
+    dom = 1 + int(np.argmax(iso_ms[1:]))
+    dom_name = names[dom]
+    dom_bytes = alg[dom_name] * Bs if alg[dom_name] else 4 * 4000 * Bs
+    achieved = dom_bytes / (float(stage_ms[dom]) * 1e-3) / 1e9
+    traffic, insts, src = committed_counters(KERNEL_OF_STAGE[dom_name], Bs)
+    valu = None
+    if insts:
+        peak, peak_src = measured_issue_peak()
+        rate = insts / (float(iso_ms[dom]) * 1e-3)
+        valu = {"wave_instructions_per_launch": insts, "achieved_Ginstr_per_s": rate / 1e9,
+                "peak_Ginstr_per_s": None if peak is None else peak / 1e9, "frac": None if peak is None else rate / peak,
+                "peak_source": peak_src}
+    frame_alg = W * H + (P - W * H) + P + 2 * P + int(kp_mean * 60)
+    out = bench_line(
+        "frames/sec ORB extract+match at 640x480/1000 kp", "frames/s", world * B * args.steps / wall_max, world, args.steps,
+        args.warmup, wall_max, "weak", "u8", "synthetic",
+        {"workload": "TUM mono 640x480, 1000 features, 8 levels, scale 1.2, FAST 20/7: extract + SearchByProjection(Cur,Last) "
+                     "th=15 against the previous frame",
+         "batch_per_gpu": B, "streams": S, "keypoints_per_frame": kp_mean, "matches_per_frame": nm_mean,
+         "parallelism": "every rank its own sequence on its own GPU (%d), no collective" % world},
+        roofline={"bound": "hbm", "kernel": KERNEL_OF_STAGE[dom_name], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
+                  "launch_ms": float(stage_ms[dom]), "launch_ms_isolated": float(iso_ms[dom]),
+                  "achieved_isolated": dom_bytes / (float(iso_ms[dom]) * 1e-3) / 1e9, "valu_issue": valu,
+                  "source": {"achieved": "HIP events in this run", "traffic_and_instruction_counts": src + ["builder-run rocprofv3 --pmc passes"]},
+                  "note": "integer byte kernel: its HBM traffic is at the algorithmic volume, the time goes into vector instructions "
+                          "(valu_issue: instructions per launch over the isolated launch time, against the measured issue rate)"},
+        stages_ms_per_step={n: float(v) for n, v in zip(names, stage_ms)},
+        stages_ms_isolated={n: float(v) for n, v in zip(names, iso_ms)},
+        extract_algorithmic_GBps=frame_alg * Bs / (float(iso_ms.sum()) * 1e-3) / 1e9,
+        step_algorithmic_GBps=frame_alg * world * B * args.steps / wall_max / 1e9,
+        window_resolver_iterations_rescans=wstats)
 
-    latency = None
-    if rank == 0 and not args.no_latency:
-        # single-frame latency through the host-pointer API (H2D image, D2H features, sync): not part of `value`
+    if world == 1 and not args.no_latency:
+        # what a host caller sees: (1) one frame through the host-pointer C ABI; (2) a batch of host images in, host
+        # keypoints + descriptors out (PCIe both ways) -- never the reported `value`
         ex1 = api.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H)
         mt1 = api.ORBmatcher(0.9, True, device=local_rank)
         k0, d0 = ex1(frames[0]); k1, d1 = ex1(frames[1])
@@ -210,92 +428,120 @@ def main():
         for _ in range(50):
             mt1.SearchByProjection(api.MODE_LAST_FRAME, q1, d0, k1, d1, bounds)
         t3 = time.perf_counter()
-        latency = {"extract_ms": (t2 - t1) / 50 * 1e3, "match_ms": (t3 - t2) / 50 * 1e3,
-                   "note": "one frame through the host-pointer C ABI incl. PCIe both ways and the Python call"}
+        out["single_frame_latency"] = {"extract_ms": (t2 - t1) / 50 * 1e3, "match_ms": (t3 - t2) / 50 * 1e3,
+                                       "note": "one frame through the host-pointer C ABI incl. PCIe both ways and the Python call",
+                                       "cpp": cpp_latency(frames)}
+        nb = min(512, B)
+        exb = api.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H, max_batch=nb)
+        exb.extract_batch(frames[:nb])
+        t4 = time.perf_counter()
+        for _ in range(3):
+            exb.extract_batch(frames[:nb])
+        out["pcie_inclusive_frames_per_s"] = {"value": 3 * nb / (time.perf_counter() - t4), "frames_per_call": nb,
+                                              "note": "orbgpu_extract_batch: pageable host images in, keypoints + descriptors "
+                                                      "out to host memory, through the Python wrapper; extraction only"}
+    return out
 
+
+def run_4k(args, rank, local_rank, world, torch, dev, barrier):
+    """256 frames 3840x2160 / 8000 features, extraction only, sharded over the ranks in contiguous chunks."""
+    from orb_slam2_amd import api, synth
+    from orb_slam2_amd.dist import max_over_ranks, shard_frames
+    w, h, nfeat, total = 3840, 2160, 8000, args.frames_4k
+    mine = shard_frames(total, world, rank)
+    n = len(mine)
+    distinct = synth.sequence(w, h, 4, seed=4, n_shapes=3000)  # four distinct frames, cycled by global frame index
+    idx = torch.tensor([g % 4 for g in mine], dtype=torch.long)
+    d_imgs = torch.from_numpy(distinct).to(dev)[idx.to(dev)].contiguous()
+    per_launch = min(n, args.launch_4k)
+    ex = api.ORBextractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=w, max_height=h, max_batch=per_launch)
+    cap = ex.max_keypoints
+    d_k = torch.zeros((n, cap, 28), dtype=torch.uint8, device=dev)
+    d_d = torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev)
+    d_c = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def step():
+        for lo in range(0, n, per_launch):
+            m = min(per_launch, n - lo)
+            ex.extract_batch_device(d_imgs[lo].data_ptr(), m, w, h, w, w * h, d_k[lo].data_ptr(), d_d[lo].data_ptr(), cap,
+                                    d_c[lo:].data_ptr())
+
+    def sync():
+        ex.sync()
+        torch.cuda.synchronize(dev)
+
+    wall = timed_steps(step, args.steps, args.warmup, sync, barrier)
+    wall_max = max_over_ranks(wall, dev if world > 1 else None)
+    ex.profile(2)
+    step(); sync()
+    iso_ms, _ = ex.stage_times()
+    ex.profile(False)
+    if rank != 0:
+        return None
+    kp_mean = float(d_c.float().mean().item())
+    P, _ = level_pixels(w, h)
+    frame_alg = w * h + (P - w * h) + P + 2 * P + int(kp_mean * 60)
+    names = ["pyramid", "fast_cells", "octree", "blur", "describe"]
+    dom = 1 + int(np.argmax(iso_ms[1:]))
+    alg = {"fast_cells": P, "octree": 4 * 32000, "blur": 2 * P, "describe": int(kp_mean * 60)}[names[dom]]
+    m_last = n - (n - 1) // per_launch * per_launch  # frames of the launch the isolated pass timed last
+    achieved = alg * m_last / (float(iso_ms[dom]) * 1e-3) / 1e9
+    return bench_line(
+        "frames/sec ORB extract at 3840x2160/8000 kp", "frames/s", total * args.steps / wall_max, world, args.steps, args.warmup,
+        wall_max, "strong", "u8", "synthetic (4 distinct frames cycled)",
+        {"workload": "256-frame batch 3840x2160, 8000 features, 8 levels: extraction, device-resident, frames sharded in contiguous "
+                     "chunks across the ranks",
+         "frames_total": total, "frames_this_rank": n, "frames_per_launch": per_launch, "keypoints_per_frame": kp_mean,
+         "parallelism": "%d rank(s), no collective" % world},
+        roofline={"bound": "hbm", "kernel": KERNEL_OF_STAGE[names[dom]], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms_isolated": float(iso_ms[dom]),
+                  "source": {"achieved": "HIP events in this run (launches timed alone after the timed region)"}},
+        stages_ms_isolated={nm: float(v) for nm, v in zip(names, iso_ms)},
+        step_algorithmic_GBps=frame_alg * total * args.steps / wall_max / 1e9)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["tum", "4k"], default="tum")
+    ap.add_argument("--batch", type=int, default=2048, help="tum: frames per step and GPU")
+    ap.add_argument("--streams", type=int, default=4, help="tum: independent sub-pipelines (HIP streams) the batch is split over")
+    ap.add_argument("--frames-4k", type=int, default=256, help="4k: frames of the whole job per step")
+    ap.add_argument("--launch-4k", type=int, default=64, help="4k: frames per launch")
+    ap.add_argument("--no-latency", action="store_true", help="skip the host-side latency / PCIe probes (profiling runs)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher: this process starts the ranks and relays rank 0's line; it must not touch the GPU itself
+        rc, out0 = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        sys.exit(rc)
+
+    import torch
+    import torch.distributed as dist
+    from orb_slam2_amd.dist import env_world
+    _, local_rank, _ = env_world()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    rank, local_rank, world = init_ranks("nccl", dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    run = run_tum if args.workload == "tum" else run_4k
+    out = run(args, rank, local_rank, world, torch, dev, barrier)
     if rank == 0:
-        P, sizes = level_pixels(W, H)
-        # algorithmic HBM bytes per frame of each extractor stage
-        alg = {
-            "pyramid": W * H + P,            # read the input, write every level once
-            "fast_cells": P,                 # read every level once
-            "octree": 0,
-            "blur": 2 * P,                   # read + write every level
-            "describe": int(kp_mean * 60),   # 28 B keypoint + 32 B descriptor per feature
-        }
-        names = ["pyramid", "fast_cells", "octree", "blur", "describe"]
-        # the blur runs on a side stream beside the quadtree: main-stream time = everything but the blur
-        match_ms = gpu_ms / args.steps - float(stage_ms.sum() - stage_ms[3]) if S == 1 else None
-        # dominant kernel = the single-launch stage with the longest isolated time (the pyramid stage is a chain of nine launches)
-        dom = 1 + int(np.argmax(iso_ms[1:]))
-        dom_name = names[dom]
-        # the quadtree moves O(N) bytes; price it (if dominant) by the candidate bytes it gathers
-        dom_bytes = alg[dom_name] * Bs if alg[dom_name] else 4 * 4000 * Bs
-        achieved = dom_bytes / (float(stage_ms[dom]) * 1e-3) / 1e9
-        # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (same batch size only)
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pm.get("batch") == Bs:
-                kk = pm["kernels"][{"pyramid": "k_pyr_resize", "fast_cells": "k_fast_cells", "octree": "k_octree_batch", "blur": "k_blur",
-                                    "describe": "k_describe"}[dom_name]]
-                traffic = (kk["FETCH_SIZE_KB_per_launch"] * kk.get("fetch_corr", 1.0) + kk["WRITE_SIZE_KB_per_launch"]) * 1024
-        except Exception:
-            traffic = None
-        # vector-issue view of the same kernel: SQ_INSTS_VALU per launch from the committed PMC pass (same launch size
-        # only) over the isolated launch time, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 integer instruction
-        valu = None
-        try:
-            if Bs == 512:
-                kname = {"pyramid": "k_pyr_resize", "fast_cells": "k_fast_cells", "octree": "k_octree_batch", "blur": "k_blur",
-                         "describe": "k_describe"}[dom_name]
-                for line in open(os.path.join(ROOT, "profiles", "r01_sq_counters.txt")):
-                    f = line.split()
-                    if f and f[0] == kname:
-                        insts = float(f[2])
-                        peak = 1024 * 2.4e9 / 4
-                        valu = {"wave_instructions_per_launch": insts, "achieved_Ginstr_per_s": insts / (float(iso_ms[dom]) * 1e-3) / 1e9,
-                                "peak_Ginstr_per_s": peak / 1e9, "frac": insts / (float(iso_ms[dom]) * 1e-3) / peak}
-        except Exception:
-            valu = None
-        frame_alg = W * H + (P - W * H) + P + 2 * P + int(kp_mean * 60)
-        out = {
-            "metric": "frames/sec ORB extract+match at 640x480/1000 kp",
-            "value": world * B * args.steps / wall_max,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall_max / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": "TUM mono 640x480, 1000 features, 8 levels, scale 1.2, FAST 20/7: extract + "
-                                   "SearchByProjection(Cur,Last) th=15 against the previous frame",
-                       "batch_per_gpu": B, "streams": S, "keypoints_per_frame": kp_mean, "matches_per_frame": nm_mean,
-                       "parallelism": "frames sharded across %d GPU(s), no collective" % world + (" (REHEARSAL: all ranks on one device)" if rehearsal else "")},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": float(stage_ms[dom]),
-                         "launch_ms_isolated": float(iso_ms[dom]), "achieved_isolated": dom_bytes / (float(iso_ms[dom]) * 1e-3) / 1e9,
-                         "valu_issue": valu,
-                         "note": "integer byte kernels: the binding limit is vector-ALU issue (1 wave-instr / 4 cycles / SIMD), "
-                                 "see profiles/r01_sq_counters.txt; traffic = committed rocprofv3 PMC passes of this workload"},
-            "stages_ms_per_step": dict({n: float(v) for n, v in zip(names, stage_ms)}, match=match_ms),
-            "stages_ms_isolated": {n: float(v) for n, v in zip(names, iso_ms)},
-            "extract_algorithmic_GBps": frame_alg * Bs / (float(stage_ms.sum()) * 1e-3) / 1e9,
-            "gpu_ms_per_step": gpu_ms / args.steps,
-            "window_resolver_iterations_rescans": wstats,
-            "single_frame_latency": latency,
-        }
-        if args.cpu_frames > 0 and world == 1:
-            fps, dt = cpu_baseline(frames, args.cpu_frames)
-            out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%d frames of the same sequence, extract + windowed match, %.1f s" % (args.cpu_frames, dt)}
-        elif world == 1:
-            out["cpu_baseline"] = None
+        if world == 1 and args.workload == "tum":
+            if args.no_cpu:
+                out["cpu_baseline"] = None
+            else:
+                from orb_slam2_amd import synth
+                out["cpu_baseline"] = cpu_baseline(synth.sequence(W, H, 64, seed=1, step=STEP, per_frame_density=True))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

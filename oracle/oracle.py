@@ -204,10 +204,8 @@ class Extractor:
             return None
         buf = (C.c_uint8 * (st.value * (h.value - 1) + w.value)).from_address(ptr.value)
         arr = np.frombuffer(buf, np.uint8)
-        out = np.zeros((h.value, w.value), np.uint8)
-        for y in range(h.value):
-            out[y] = arr[y * st.value:y * st.value + w.value]
-        return out
+        view = np.lib.stride_tricks.as_strided(arr, shape=(h.value, w.value), strides=(st.value, 1), writeable=False)
+        return np.ascontiguousarray(view)
 
     def level_count(self, level):
         return lib().orc_extractor_level_count(self.h, level)

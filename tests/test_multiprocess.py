@@ -43,3 +43,26 @@ def test_two_ranks_shard_and_reduce():
     assert (a0, b0, a1, b1) == (0, 50, 51, 100)      # contiguous, disjoint, covering
     assert t0 == t1 == 2.0                            # the slowest rank's time everywhere
     assert n0 == n1 == 101.0                          # whole-job frame count
+
+
+def test_bench_launcher_starts_ranks_and_relays_rank0():
+    """bench.py --gpus N without torchrun: the launcher starts N rank processes with the torchrun environment and
+    prints rank 0's line.  Driven here with 2 gloo ranks and a stub step on the CPU."""
+    import json
+    import bench
+    rc, out = bench.spawn_ranks(2, [sys.executable, os.path.join(ROOT, "tests", "stub_bench_rank.py")], timeout=240)
+    assert rc == 0, out
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 2 and line["scaling"] == "strong"
+    cfg = line["config"]
+    assert (cfg["first"], cfg["last"], cfg["covered"]) == (0, 127, 256.0)
+    # the slowest rank (0.02 s per step) sets the time; rank 0 alone would have needed half of it
+    assert cfg["slowest_rank_s"] >= 5 * 0.02 and cfg["slowest_rank_s"] >= cfg["this_rank_s"]
+    assert abs(line["value"] - 256 * 5 / cfg["slowest_rank_s"]) < 1e-6 * line["value"]
+    assert abs(line["ms_per_step"] - cfg["slowest_rank_s"] / 5 * 1e3) < 1e-9
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    import bench
+    rc, _ = bench.spawn_ranks(2, [sys.executable, "-c", "import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)"], timeout=60)
+    assert rc == 3
