@@ -69,6 +69,11 @@ typedef struct orbgpu_matcher orbgpu_matcher;
 const char *orbgpu_last_error(void); /* thread-local description of the last failure */
 int orbgpu_device_count(int *count);
 
+/* Page-locked host memory for the batch entry points (no counterpart in the
+ * reference): the GPU reads and writes it directly, without a staging copy. */
+int orbgpu_pinned_alloc(size_t bytes, void **out);
+void orbgpu_pinned_free(void *p);
+
 /* ---- ORBextractor ------------------------------------------------------- */
 
 /* ORBextractor::ORBextractor (src/ORBextractor.cc:456-577). */
@@ -116,7 +121,15 @@ int orbgpu_extract(orbgpu_extractor *e, const uint8_t *img, int32_t w, int32_t h
                    int32_t *n_out);
 
 /* Batch of host images, all w x h: frame f outputs start at kps + f*capacity,
- * desc + f*capacity*32; counts[f] keypoints are valid. */
+ * desc + f*capacity*32; counts[f] keypoints are valid.  Batches of 32 frames and
+ * more are cut into chunks whose uploads, kernels and downloads overlap.  Memory
+ * that is already page-locked (orbgpu_pinned_alloc, hipHostMalloc,
+ * hipHostRegister) is used in place: contiguous page-locked frames (imgs[f + 1]
+ * == imgs[f] + w*h, stride == w) are uploaded without a staging copy, and with
+ * capacity == orbgpu_extractor_max_keypoints the results are written straight
+ * into page-locked kps / desc (rows beyond counts[f] then hold unspecified
+ * bytes).  Pageable memory goes through the handle's own staging buffers, copied
+ * by a few host threads. */
 int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg,
                          int32_t w, int32_t h, int32_t stride, orbgpu_keypoint *kps,
                          uint8_t *desc, int32_t capacity, int32_t *counts);

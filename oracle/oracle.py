@@ -214,6 +214,12 @@ class Extractor:
         return lib().orc_extractor_tie_straddles(self.h)
 
 
+def set_tie_rule(rule):
+    """Order of equal-sized quadtree nodes in the partial passes: 0 = latest created first (what the GPU implements),
+    1 = earliest first.  The reference orders by heap address (src/ORBextractor.cc:906); rule 1 measures the dependence."""
+    lib().orc_set_tie_rule(int(rule))
+
+
 def bruteforce(Q, T):
     Q = np.ascontiguousarray(Q, np.uint8); T = np.ascontiguousarray(T, np.uint8)
     nq, nt = len(Q), len(T)

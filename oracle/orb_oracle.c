@@ -505,11 +505,18 @@ static int q_divide(qlist *L, int id, const float *xs, const float *ys, int *exp
 }
 
 typedef struct { int count, seq, id; } size_entry;
+/* Order among nodes of equal size in the partial passes.  The reference sorts pair<int, ExtractorNode*>
+ * (src/ORBextractor.cc:906), i.e. by heap address, which no restatement can know.  Rule 0 (the one the GPU path
+ * implements): the node created last is split first.  Rule 1: the node created first is split first -- only used to
+ * measure how much of the output depends on the order (orc_set_tie_rule). */
+static int g_tie_rule = 0;
+void orc_set_tie_rule(int rule) { g_tie_rule = rule; }
 static int size_entry_cmp(const void *a, const void *b)
 {
     const size_entry *x = (const size_entry *)a, *y = (const size_entry *)b;
     if (x->count != y->count) return x->count < y->count ? -1 : 1;
-    return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
+    const int c = x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
+    return g_tie_rule ? -c : c;
 }
 
 int orc_distribute_octree(const float *xs, const float *ys, const float *resp, int n,

@@ -127,6 +127,11 @@ int orc_features_in_area_geom(const orc_keypoint *kps, const float *geom6, const
                               const int32_t *cell_items, float x, float y, float r, int minLevel, int maxLevel,
                               int32_t *out, int cap);
 
+/* Tie order of equal-sized nodes in the partial passes of orc_distribute_octree: 0 (default) = latest created first,
+ * 1 = earliest created first.  The reference orders them by heap address (src/ORBextractor.cc:906); rule 1 exists to
+ * measure how much of the selection depends on that order.  Process-wide, not thread-safe: measurement only. */
+void orc_set_tie_rule(int rule);
+
 /* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1661-1704) on bin sizes. */
 void orc_three_maxima(const int *sizes, int L, int *ind1, int *ind2, int *ind3);
 

@@ -29,7 +29,7 @@ MODE_LOCAL_MAP, MODE_LAST_FRAME, MODE_KEYFRAME = 0, 1, 2
 
 # every symbol include/orbgpu.h declares
 EXPORTS = [
-    "orbgpu_last_error", "orbgpu_device_count",
+    "orbgpu_last_error", "orbgpu_device_count", "orbgpu_pinned_alloc", "orbgpu_pinned_free",
     "orbgpu_extractor_create", "orbgpu_extractor_destroy", "orbgpu_extractor_set_stream", "orbgpu_extractor_sync",
     "orbgpu_extractor_status", "orbgpu_extractor_profile", "orbgpu_extractor_stage_times",
     "orbgpu_extractor_tables", "orbgpu_extractor_max_keypoints", "orbgpu_extract", "orbgpu_extract_batch",
@@ -70,6 +70,9 @@ def load_library():
         L = C.CDLL(LIB_PATH)
         L.orbgpu_last_error.restype = C.c_char_p
         vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+        L.orbgpu_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+        L.orbgpu_pinned_free.argtypes = [vp]
+        L.orbgpu_pinned_free.restype = None
         L.orbgpu_extractor_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
         L.orbgpu_extractor_destroy.argtypes = [vp]
         L.orbgpu_extractor_destroy.restype = None
@@ -136,6 +139,28 @@ def _check(rc, what):
 
 def _p(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class _Pinned:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            load_library().orbgpu_pinned_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """A numpy array in page-locked host memory (orbgpu_pinned_alloc); freed with the array."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = C.c_void_p()
+    _check(load_library().orbgpu_pinned_alloc(max(n, 1), C.byref(p)), "orbgpu_pinned_alloc")
+    buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+    buf._owner = _Pinned(p)  # the array keeps the ctypes buffer alive, the buffer keeps the allocation
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
 def device_count():
@@ -206,6 +231,17 @@ class ORBextractor:
         _check(self._lib.orbgpu_extract_batch(self._h, ptrs, B, w, h, images.strides[1], _p(kps), _p(desc), cap,
                                               _p(counts)), "orbgpu_extract_batch")
         return [(kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(B)]
+
+    def extract_batch_into(self, images, kps, desc, counts):
+        """orbgpu_extract_batch into caller-owned arrays: images uint8 [B,h,w] contiguous, kps [B,cap] of KEYPOINT_DTYPE,
+        desc uint8 [B,cap,32], counts int32 [B].  Nothing is allocated or copied on the Python side; page-locked
+        arrays (pinned_empty) are used by the GPU in place."""
+        B, h, w = images.shape
+        cap = kps.shape[1]
+        assert images.dtype == np.uint8 and images.flags.c_contiguous and kps.flags.c_contiguous and desc.flags.c_contiguous
+        assert kps.dtype == KEYPOINT_DTYPE and desc.shape == (B, cap, 32) and counts.dtype == np.int32 and len(counts) == B
+        ptrs = (C.c_void_p * B)(*[images.ctypes.data + i * h * w for i in range(B)])
+        _check(self._lib.orbgpu_extract_batch(self._h, ptrs, B, w, h, w, _p(kps), _p(desc), cap, _p(counts)), "orbgpu_extract_batch")
 
     def extract_batch_device(self, d_imgs_ptr, nimg, w, h, stride, frame_stride, d_kps_ptr, d_desc_ptr, capacity,
                              d_counts_ptr):

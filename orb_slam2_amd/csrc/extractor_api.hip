@@ -7,7 +7,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -69,6 +72,82 @@ struct DevBuf {
     }
 };
 
+// A few persistent host threads for the per-frame copies of the host batch entry points (staging pageable images
+// into pinned memory, handing results out): started with the handle's first large batch, joined with the handle.
+// One thread moves only a few GB/s, and starting threads per call costs more than the copies of a small chunk.
+class CopyPool {
+public:
+    explicit CopyPool(int nthreads)
+    {
+        for (int t = 0; t < nthreads; t++) workers_.emplace_back([this]() { loop(); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_ = true;
+        }
+        wake_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    // fn(i) for i in [0, n), on the workers and the calling thread; returns when all are done
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 0) return;
+        unsigned gen;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; n_ = n; next_ = 0; pending_ = n;
+            gen = ++generation_;
+        }
+        wake_.notify_all();
+        work(gen);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this]() { return pending_ == 0; });
+    }
+
+private:
+    // items are whole frames (hundreds of KB each), so handing them out under the mutex costs nothing; a worker that
+    // is still leaving an earlier run can never take an item of the current one under the old run's terms
+    void work(unsigned gen)
+    {
+        for (;;) {
+            const std::function<void(int)> *fn;
+            int i;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (generation_ != gen || next_ >= n_) return;
+                i = next_++;
+                fn = fn_;
+            }
+            (*fn)(i);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop()
+    {
+        unsigned seen = 0;
+        for (;;) {
+            unsigned gen;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                wake_.wait(lk, [&]() { return quit_ || (generation_ != seen && next_ < n_); });
+                if (quit_) return;
+                seen = gen = generation_;
+            }
+            work(gen);
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int next_ = 0, n_ = 0, pending_ = 0;
+    unsigned generation_ = 0;
+    bool quit_ = false;
+};
+
 }  // namespace orbgpu
 
 using namespace orbgpu;
@@ -96,6 +175,10 @@ struct orbgpu_extractor {
     DevBuf st_img, st_kps, st_desc, st_counts;  // staging for the host entry points
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
+    // chunked host batches: uploads and downloads on their own streams beside the kernels
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    std::vector<hipEvent_t> chunk_ev;  // three per chunk: uploaded, extracted, downloaded
+    CopyPool *pool = nullptr;
     // optional stage timing: a ring of event sets, one set per extract call
     bool profile = false;
     bool serialize = false;  // profiling mode 2: the blur stays on the main stream so every stage is timed alone
@@ -405,6 +488,23 @@ int orbgpu_device_count(int *count)
     return ORBGPU_OK;
 }
 
+int orbgpu_pinned_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) return ORBGPU_E_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipHostMalloc of %zu bytes failed", bytes);
+        return ORBGPU_E_NOMEM;
+    }
+    return ORBGPU_OK;
+}
+
+void orbgpu_pinned_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int orbgpu_extractor_create(const orbgpu_params *p, orbgpu_extractor **out)
 {
     if (!p || !out) return ORBGPU_E_INVALID;
@@ -460,6 +560,10 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e)
     for (DevBuf *b : bufs) b->release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
+    for (hipEvent_t x : e->chunk_ev) (void)hipEventDestroy(x);
+    delete e->pool;
+    if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
+    if (e->down_stream) (void)hipStreamDestroy(e->down_stream);
     if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -577,6 +681,11 @@ static void drop_graph(orbgpu_extractor *e)
     e->graph_nimg = 0;
 }
 
+// Enqueue the extraction of nimg device-resident frames as frames frame0 .. frame0 + nimg - 1 of the handle's working
+// set (pyramids, candidate slots, quadtree storage are per frame), on the handle's stream.
+static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_imgs, int32_t nimg, int32_t stride, size_t frame_stride,
+                           orbgpu_keypoint *d_kps, uint8_t *d_desc, int32_t capacity, int32_t *d_counts, bool clear_status);
+
 int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int32_t nimg, int32_t w, int32_t h,
                                 int32_t stride, size_t frame_stride, orbgpu_keypoint *d_kps, uint8_t *d_desc,
                                 int32_t capacity, int32_t *d_counts)
@@ -592,8 +701,23 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
     ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
     int rc = set_geometry(e, w, h);
     if (rc) return rc;
+    return enqueue_extract(e, 0, d_imgs, nimg, stride, frame_stride, d_kps, d_desc, capacity, d_counts, true);
+}
+
+static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_imgs, int32_t nimg, int32_t stride, size_t frame_stride,
+                           orbgpu_keypoint *d_kps, uint8_t *d_desc, int32_t capacity, int32_t *d_counts, bool clear_status)
+{
+    int rc;
     const Geom &G = e->G;
     hipStream_t st = e->stream;
+    const size_t f0 = (size_t)frame0;
+    uint8_t *pyr = (uint8_t *)e->pyr.p + f0 * (size_t)G.pyr_frame_bytes, *blur = (uint8_t *)e->blur.p + f0 * (size_t)G.pyr_frame_bytes;
+    uint32_t *slots = (uint32_t *)e->slots.p + f0 * (size_t)G.slot_frame_u32, *cand = (uint32_t *)e->cand.p + f0 * (size_t)G.cand_frame_u32;
+    int32_t *cell_counts = (int32_t *)e->cell_counts.p + f0 * (size_t)G.total_cells;
+    QNode *nodes = (QNode *)e->nodes.p + f0 * (size_t)G.node_frame;
+    int32_t *scratch = (int32_t *)e->scratch.p + f0 * (size_t)G.node_frame * 4;
+    uint32_t *sel = (uint32_t *)e->sel.p + f0 * (size_t)G.total_kp_cap;
+    int32_t *sel_count = (int32_t *)e->sel_count.p + f0 * (size_t)G.nlevels, *cand_count = (int32_t *)e->cand_count.p + f0 * (size_t)G.nlevels;
     hipEvent_t *ev = nullptr;
     if (e->profile) {
         ev = &e->ev[(size_t)e->prof_next * kProfEvents];
@@ -601,15 +725,13 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
         if (e->prof_used < kProfSets) e->prof_used++;
     }
 #define STAGE_MARK(i) do { if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[i], st)); } while (0)
-    // the status word describes this call alone (a captured sequence clears it on every replay as well)
-    ORBGPU_HIP_CHECK(hipMemsetAsync(e->status.p, 0, 4, st));
+    // the status word describes one call alone (a captured sequence clears it on every replay as well)
+    if (clear_status) ORBGPU_HIP_CHECK(hipMemsetAsync(e->status.p, 0, 4, st));
     STAGE_MARK(0);
-    if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, (uint8_t *)e->pyr.p, G, (const XTab *)e->xtab.p,
-                             (const YTab *)e->ytab.p)))
+    if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, pyr, G, (const XTab *)e->xtab.p, (const YTab *)e->ytab.p)))
         return rc;
     STAGE_MARK(1);
-    if ((rc = launch_fast(st, nimg, (const uint8_t *)e->pyr.p, G, (const uint32_t *)e->cell_tab.p, (uint32_t *)e->slots.p,
-                          (int32_t *)e->cell_counts.p))) return rc;
+    if ((rc = launch_fast(st, nimg, pyr, G, (const uint32_t *)e->cell_tab.p, slots, cell_counts))) return rc;
     STAGE_MARK(2);
     // fork: the blur depends on the pyramid only.  FAST keeps every SIMD busy, the
     // quadtree is latency-bound, so the blur is released after FAST to run beside the quadtree
@@ -619,23 +741,141 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
         ORBGPU_HIP_CHECK(hipStreamWaitEvent(ax, e->ev_fork, 0));
     }
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], ax));
-    if ((rc = launch_blur(ax, nimg, (const uint8_t *)e->pyr.p, (uint8_t *)e->blur.p, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
+    if ((rc = launch_blur(ax, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
     if (!e->serialize) ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
-    if ((rc = launch_octree(st, nimg, G, (const uint32_t *)e->slots.p, (const int32_t *)e->cell_counts.p, (uint32_t *)e->cand.p,
-                            (QNode *)e->nodes.p, (int32_t *)e->scratch.p, (uint32_t *)e->sel.p, (int32_t *)e->sel_count.p,
-                            (int32_t *)e->cand_count.p, (int32_t *)e->status.p)))
+    if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, (int32_t *)e->status.p)))
         return rc;
     STAGE_MARK(3);
     if (!e->serialize) ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
-    if ((rc = launch_describe(st, nimg, (const uint8_t *)e->pyr.p, (const uint8_t *)e->blur.p, G, (const uint32_t *)e->sel.p,
-                              (const int32_t *)e->sel_count.p, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts,
-                              capacity, (int32_t *)e->status.p)))
+    if ((rc = launch_describe(st, nimg, pyr, blur, G, sel, sel_count, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts, capacity,
+                              (int32_t *)e->status.p)))
         return rc;
     STAGE_MARK(4);
 #undef STAGE_MARK
-    e->last_nimg = nimg;
+    e->last_nimg = frame0 + nimg;
     e->halo_full = false;
+    return ORBGPU_OK;
+}
+
+// Is p host memory that the GPU can reach by DMA (hipHostMalloc / hipHostRegister)?  Pageable memory is unknown to
+// the runtime, which reports an error for it.
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    const hipError_t rc = hipPointerGetAttributes(&a, p);
+    (void)hipGetLastError();
+    return rc == hipSuccess && a.type == hipMemoryTypeHost;
+}
+
+static constexpr int kChunkMin = 32;  // host batches of at least this many frames are cut into chunks
+
+// Large host batches: the frames are cut into chunks, and while the kernels of chunk k run, chunk k + 1 is uploaded
+// and the results of chunk k - 1 are downloaded on two further streams; the host meanwhile stages chunk k + 2 into
+// pinned memory and hands out the results of chunk k - 2.  Caller memory that is already pinned (hipHostMalloc,
+// hipHostRegister) is used in place: contiguous pinned frames go to the device in one copy per chunk without
+// staging, and with capacity == the handle's own bound the results land in the caller's arrays directly.
+static int extract_batch_chunked(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h, int32_t stride,
+                                 orbgpu_keypoint *kps, uint8_t *desc, int32_t capacity, int32_t *counts)
+{
+    const int cap = e->G.total_kp_cap;
+    const size_t fbytes = (size_t)w * h;
+    int chunk = std::max(kChunkMin / 2, (nimg + 7) / 8);
+    const int nchunks = (nimg + chunk - 1) / chunk;
+    if (!e->up_stream) {
+        ORBGPU_HIP_CHECK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
+        ORBGPU_HIP_CHECK(hipStreamCreateWithFlags(&e->down_stream, hipStreamNonBlocking));
+    }
+    if (!e->pool) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        e->pool = new (std::nothrow) CopyPool((int)std::min(15u, hw > 1 ? hw - 1 : 1u));
+        if (!e->pool) return ORBGPU_E_NOMEM;
+    }
+    while ((int)e->chunk_ev.size() < 3 * nchunks) {
+        hipEvent_t x;
+        ORBGPU_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+        e->chunk_ev.push_back(x);
+    }
+    bool contiguous = stride == w;
+    for (int f = 1; f < nimg && contiguous; f++) contiguous = imgs[f] == imgs[f - 1] + fbytes;
+    const bool in_pinned = contiguous && is_pinned_host(imgs[0]) && is_pinned_host(imgs[0] + fbytes * (size_t)nimg - 1);
+    const bool out_direct = capacity == cap && is_pinned_host(kps) && is_pinned_host(desc);
+    uint8_t *hp = (uint8_t *)e->h_pinned;
+    orbgpu_keypoint *h_kps = (orbgpu_keypoint *)hp;
+    uint8_t *h_desc = hp + (size_t)e->p.max_batch * cap * sizeof(orbgpu_keypoint);
+    int32_t *h_counts = (int32_t *)(h_desc + (size_t)e->p.max_batch * cap * 32);
+    int32_t *h_status = h_counts + e->p.max_batch;
+    uint8_t *h_in = (uint8_t *)(h_status + 16);
+    hipStream_t st = e->stream;
+    ORBGPU_HIP_CHECK(hipMemsetAsync(e->status.p, 0, 4, st));
+    int rc = ORBGPU_OK;
+
+    auto stage_in = [&](int c) {  // pageable frames of chunk c -> pinned
+        const int f0 = c * chunk, n = std::min(chunk, nimg - f0);
+        e->pool->run(n, [&](int i) {
+            const int f = f0 + i;
+            uint8_t *dst = h_in + (size_t)f * fbytes;
+            if (stride == w) memcpy(dst, imgs[f], fbytes);
+            else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, imgs[f] + (size_t)y * stride, (size_t)w);
+        });
+    };
+    auto hand_out = [&](int c) -> int {  // results of chunk c (downloaded) -> the caller's arrays
+        const int f0 = c * chunk, n = std::min(chunk, nimg - f0);
+        ORBGPU_HIP_CHECK(hipEventSynchronize(e->chunk_ev[3 * c + 2]));
+        for (int i = 0; i < n; i++) {
+            const int cnt = h_counts[f0 + i];
+            if (cnt > capacity) {
+                set_error("frame %d has %d keypoints but capacity is %d", f0 + i, cnt, capacity);
+                return ORBGPU_E_CAPACITY;
+            }
+            counts[f0 + i] = cnt;
+        }
+        if (!out_direct)
+            e->pool->run(n, [&](int i) {
+                const int f = f0 + i, cnt = h_counts[f];
+                memcpy(kps + (size_t)f * capacity, h_kps + (size_t)f * cap, (size_t)cnt * sizeof(orbgpu_keypoint));
+                memcpy(desc + (size_t)f * capacity * 32, h_desc + (size_t)f * cap * 32, (size_t)cnt * 32);
+            });
+        return ORBGPU_OK;
+    };
+
+    if (!in_pinned) stage_in(0);
+    for (int c = 0; c < nchunks && rc == ORBGPU_OK; c++) {
+        const int f0 = c * chunk, n = std::min(chunk, nimg - f0);
+        hipEvent_t ev_up = e->chunk_ev[3 * c], ev_done = e->chunk_ev[3 * c + 1], ev_down = e->chunk_ev[3 * c + 2];
+        uint8_t *d_img = (uint8_t *)e->st_img.p + (size_t)f0 * fbytes;
+        orbgpu_keypoint *d_k = (orbgpu_keypoint *)e->st_kps.p + (size_t)f0 * cap;
+        uint8_t *d_d = (uint8_t *)e->st_desc.p + (size_t)f0 * cap * 32;
+        int32_t *d_c = (int32_t *)e->st_counts.p + f0;
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(d_img, in_pinned ? imgs[f0] : h_in + (size_t)f0 * fbytes, (size_t)n * fbytes, hipMemcpyHostToDevice,
+                                        e->up_stream));
+        ORBGPU_HIP_CHECK(hipEventRecord(ev_up, e->up_stream));
+        ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, ev_up, 0));
+        if ((rc = enqueue_extract(e, f0, d_img, n, w, fbytes, d_k, d_d, cap, d_c, false))) break;
+        ORBGPU_HIP_CHECK(hipEventRecord(ev_done, st));
+        ORBGPU_HIP_CHECK(hipStreamWaitEvent(e->down_stream, ev_done, 0));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(out_direct ? kps + (size_t)f0 * cap : h_kps + (size_t)f0 * cap, d_k, (size_t)n * cap * sizeof(orbgpu_keypoint),
+                                        hipMemcpyDeviceToHost, e->down_stream));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(out_direct ? desc + (size_t)f0 * cap * 32 : h_desc + (size_t)f0 * cap * 32, d_d, (size_t)n * cap * 32,
+                                        hipMemcpyDeviceToHost, e->down_stream));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(h_counts + f0, d_c, (size_t)n * 4, hipMemcpyDeviceToHost, e->down_stream));
+        if (c == nchunks - 1) ORBGPU_HIP_CHECK(hipMemcpyAsync(h_status, e->status.p, 4, hipMemcpyDeviceToHost, e->down_stream));
+        ORBGPU_HIP_CHECK(hipEventRecord(ev_down, e->down_stream));
+        // host work beside the GPU: the next chunk's frames, the results before last
+        if (!in_pinned && c + 1 < nchunks) stage_in(c + 1);
+        if (c >= 1) rc = hand_out(c - 1);
+    }
+    if (rc == ORBGPU_OK) rc = hand_out(nchunks - 1);
+    // everything enqueued has to finish before the handle's buffers may be reused, also after an error
+    (void)hipStreamSynchronize(e->up_stream);
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamSynchronize(e->down_stream);
+    if (rc) return rc;
+    if (*h_status) {
+        set_error("internal capacity exceeded (status %d)", *h_status);
+        return ORBGPU_E_CAPACITY;
+    }
     return ORBGPU_OK;
 }
 
@@ -659,6 +899,7 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
     // the previous call's device-to-host copies have completed (every host entry point synchronises)
     for (int f = 0; f < nimg; f++)
         if (!imgs[f]) { set_error("image %d is NULL", f); return ORBGPU_E_INVALID; }
+    if (nimg >= kChunkMin && !e->profile) return extract_batch_chunked(e, imgs, nimg, w, h, stride, kps, desc, capacity, counts);
     // pageable -> pinned on the host (a 2-D copy from pageable memory stalls for milliseconds); a batch is copied by
     // a few threads, one host thread moves only a few GB/s
     parallel_frames(nimg, [&](int f) {

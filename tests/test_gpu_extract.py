@@ -352,7 +352,13 @@ def test_randomized_sweep(oracle):
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    assert fz.main(["--cases", "120", "--seconds", "100", "--seed", "7"]) == 0
+    st = {}
+    assert fz.main(["--cases", "120", "--seconds", "100", "--seed", "7"], st) == 0
+    # Exposure to the reference's address-ordered tie-break (src/ORBextractor.cc:906,959): ties straddle the cut on many
+    # frames, but only a few percent of the keypoints depend on the order.  The GPU and the oracle agree on one order
+    # (latest-created node first); against a live reference that share of the keypoints is not pinned.
+    assert st["frames"] >= 100 and st["tie_sampled_kp"] > 0
+    assert st["tie_dependent_kp"] <= 0.06 * st["tie_sampled_kp"], st
 
 
 def test_device_call_overflow_is_reported_and_does_not_stick(oracle):
@@ -386,3 +392,91 @@ def test_device_call_overflow_is_reported_and_does_not_stick(oracle):
     n = api.C.c_int32()
     rc = ex._lib.orbgpu_extract(ex._h, api._p(img), 640, 480, 600, api._p(kps), api._p(desc), ex.max_keypoints, api.C.byref(n))
     assert rc == -1  # ORBGPU_E_INVALID: row pitch below the width
+
+
+def test_chunked_host_batches_pageable_pinned_and_strided(oracle):
+    """Host batches of 32 frames and more run as overlapped chunks; page-locked caller memory is used in place.
+    Every variant returns what frame-by-frame calls return."""
+    from orb_slam2_amd import api
+    B = 80
+    seq = synth.sequence(320, 240, B, seed=9, per_frame_density=True)
+    one = _mk(320, 240, 500)
+    ref = [one(f) for f in seq]
+    ex = _mk(320, 240, 500, max_batch=B)
+    cap = ex.max_keypoints
+
+    def check(kps, desc, counts, nb):
+        for i in range(nb):
+            n = counts[i]
+            assert n == len(ref[i][0]), i
+            assert np.array_equal(kps[i, :n], ref[i][0]) and np.array_equal(desc[i, :n], ref[i][1]), i
+
+    # pageable in, pageable out, capacity below the handle's own bound
+    out = ex.extract_batch(seq)
+    for i in range(B):
+        assert np.array_equal(out[i][0], ref[i][0]) and np.array_equal(out[i][1], ref[i][1])
+    # page-locked frames and page-locked results in place (capacity == max_keypoints), twice on the same handle
+    pimg = api.pinned_empty(seq.shape, np.uint8); pimg[...] = seq
+    pk = api.pinned_empty((B, cap), api.KEYPOINT_DTYPE); pd = api.pinned_empty((B, cap, 32), np.uint8)
+    cnt = np.zeros(B, np.int32)
+    for nb in (B, 37):
+        pk.view(np.uint8)[...] = 0xEE; cnt[:] = -1
+        ex.extract_batch_into(pimg[:nb], pk[:nb], pd[:nb], cnt[:nb])
+        check(pk, pd, cnt, nb)
+    # page-locked frames, pageable results
+    k2 = np.zeros((B, cap), api.KEYPOINT_DTYPE); d2 = np.zeros((B, cap, 32), np.uint8)
+    ex.extract_batch_into(pimg, k2, d2, cnt)
+    check(k2, d2, cnt, B)
+    # strided pageable frames (rows of a wider buffer)
+    wide = np.zeros((B, 240, 352), np.uint8); wide[:, :, 16:336] = seq
+    ptrs = (api.C.c_void_p * B)(*[wide[i, :, 16:].ctypes.data for i in range(B)])
+    api._check(ex._lib.orbgpu_extract_batch(ex._h, ptrs, B, 320, 240, 352, api._p(k2), api._p(d2), cap, api._p(cnt)), "strided")
+    check(k2, d2, cnt, B)
+    # an output capacity that is too small is reported, and the handle keeps working
+    small = np.zeros((B, 50), api.KEYPOINT_DTYPE); sd = np.zeros((B, 50, 32), np.uint8)
+    with pytest.raises(api.OrbGpuError, match="capacity"):
+        ex.extract_batch_into(seq, small, sd, cnt)
+    ex.extract_batch_into(pimg, k2, d2, cnt)
+    check(k2, d2, cnt, B)
+
+
+def test_4k_batch_of_eight_equals_single_frames(oracle):
+    """Eight 4K frames in one launch (the XCD-pinned frame / block mapping at the 4K pitch, four FAST cells per
+    workgroup, the batched quadtree): each frame equals its single-frame extraction, one of them the oracle."""
+    base = synth.sequence(3840, 2160, 2, seed=4, n_shapes=3000)
+    rng = np.random.default_rng(8)
+    frames = np.stack([np.roll(base[i % 2], (3 * i, 5 * i), (0, 1)) for i in range(8)])
+    frames[5] = (frames[5].astype(np.int16) + rng.integers(-3, 4, frames[5].shape)).clip(0, 255).astype(np.uint8)
+    ex = _mk(3840, 2160, 8000, max_batch=8)
+    res = ex.extract_batch(frames)
+    for i in range(8):
+        k1, d1 = ex(frames[i])
+        assert len(k1) > 4000
+        assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1), i
+    okps, odesc = oracle.Extractor(8000).extract(frames[5])
+    kps, desc = res[5]
+    assert len(kps) == len(okps)
+    for f in ("x", "y", "size", "response", "octave"):
+        assert np.array_equal(kps[f], okps[f]), f
+    assert int((desc != odesc).any(axis=1).sum()) <= 0.001 * len(desc)
+
+
+def test_mono_init_extractor_in_a_batch(oracle):
+    """Tracking builds a second extractor with twice the features for monocular initialisation
+    (src/Tracking.cc:168): 2000 features on 640x480, batched, against the oracle and against single frames."""
+    seq = synth.sequence(640, 480, 12, seed=5, per_frame_density=True)
+    ex = _mk(640, 480, 2000, max_batch=12)
+    assert list(ex.mnFeaturesPerLevel) == [434, 362, 302, 251, 209, 175, 145, 122]
+    res = ex.extract_batch(seq)
+    oe = oracle.Extractor(2000)
+    for i in (0, 7, 11):
+        okps, odesc = oe.extract(seq[i])
+        kps, desc = res[i]
+        assert len(kps) == len(okps) and len(kps) > 1500
+        for f in ("x", "y", "size", "response", "octave"):
+            assert np.array_equal(kps[f], okps[f]), (i, f)
+        dang = np.abs(kps["angle"] - okps["angle"])
+        assert np.minimum(dang, 360 - dang).max() <= np.degrees(1e-4)
+        assert int((desc != odesc).any(axis=1).sum()) <= 0.001 * len(desc)
+    k1, d1 = ex(seq[3])
+    assert np.array_equal(res[3][0], k1) and np.array_equal(res[3][1], d1)

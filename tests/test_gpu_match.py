@@ -489,3 +489,31 @@ def test_matcher_contexts_are_recycled():
     for got in (a.BruteForce(Q, T), b.BruteForce(Q, T)):
         assert all(np.array_equal(x, y) for x, y in zip(got, ref))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_search_by_projection_euroc_bounds(matcher, oracle, mode):
+    """EuRoC geometry: 752x480 frames, so the 64x48 grid has cells of 11.75 x 10 px (other cell-range arithmetic
+    than the 10 x 10 px cells of 640x480), 1200 features, stereo right coordinates."""
+    from orb_slam2_amd import api
+    seq = synth.sequence(752, 480, 2, seed=3)
+    oe = oracle.Extractor(1200)
+    (k1, d1), (k2, d2) = [oe.extract(f) for f in seq]
+    b = np.array([0, 0, 752, 480], np.float32)
+    sc = oracle.tables(oracle.make_params(1200))["scale"]
+    rng = np.random.default_rng(40 + mode)
+    for th in (3.0, 15.0):
+        q = api.shift_queries(k1, -2.0, -1.0, th, sc, b)
+        if mode == 0:
+            q["minLevel"] = k1["octave"] - 1; q["maxLevel"] = k1["octave"]
+        q["flags"] = np.where(rng.random(len(q)) < 0.08, q["flags"] & 1, q["flags"])
+        ur = np.where(rng.random(len(k2)) < 0.6, k2["x"] - 47.9 / 6.0, -1.0).astype(np.float32)
+        q["ur"] = q["u"] - 47.9 / 6.0 + rng.normal(0, th / 3, len(q)).astype(np.float32)
+        occ = (rng.random(len(k2)) < 0.07).astype(np.uint8)
+        q = q.astype(api.WQUERY_DTYPE)
+        matcher.mfNNratio = 0.8
+        n, assign = matcher.SearchByProjection(mode, q, d1, k2, d2, b, uright2=ur, occupied=occ, th_dist=100)
+        rn, rassign = oracle.search_by_projection(mode, q.view(oracle.WQUERY_DTYPE), d1, k2.view(oracle.KEYPOINT_DTYPE), d2, b,
+                                                  uright2=ur, occupied=occ, th_dist=100, nnratio=0.8, checkOri=True)
+        assert n == rn and np.array_equal(assign, rassign) and n > 100, (mode, th)
+    matcher.mfNNratio = 0.9

@@ -70,6 +70,22 @@ def compare_extract(ex, oe, img, stats):
     stats["desc_diff"] += nbad
     stats["desc_total"] += len(desc)
     stats["kp_total"] += len(kps)
+    # the reference breaks size ties between quadtree nodes by heap address (src/ORBextractor.cc:906): count the levels
+    # on which such a tie straddles the cut (:959) and, on a sample, the keypoints that depend on the order
+    ties = oe.tie_straddles()
+    stats["frames"] += 1
+    stats["tie_levels"] += ties
+    stats["tie_frames"] += 1 if ties else 0
+    if ties and stats["frames"] % 4 == 0:
+        O.set_tie_rule(1)
+        try:
+            akps, _ = oe.extract(img)
+        finally:
+            O.set_tie_rule(0)
+        mine = set(zip(okps["x"].tolist(), okps["y"].tolist(), okps["octave"].tolist()))
+        other = set(zip(akps["x"].tolist(), akps["y"].tolist(), akps["octave"].tolist()))
+        stats["tie_sampled_kp"] += len(mine)
+        stats["tie_dependent_kp"] += len(mine - other)
     return None, (okps, odesc)
 
 
@@ -219,7 +235,7 @@ def compare_stereo(m, exL, exR, a, b, nlevels, rng):
     return None
 
 
-def main(argv=None):
+def main(argv=None, stats_out=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=0)
@@ -227,7 +243,8 @@ def main(argv=None):
     ap.add_argument("--cases", type=int, default=1 << 30, help="stop after this many cases")
     args = ap.parse_args(argv)
     O.build()
-    stats = dict(angle_max_deg=0.0, angle_inexact=0, desc_diff=0, desc_total=0, kp_total=0)
+    stats = dict(angle_max_deg=0.0, angle_inexact=0, desc_diff=0, desc_total=0, kp_total=0, frames=0, tie_levels=0, tie_frames=0,
+                 tie_sampled_kp=0, tie_dependent_kp=0)
     t_end = time.time() + args.seconds
     case, nfail, nskip, nmatch = 0, 0, 0, 0
     m = api.ORBmatcher(0.9, True)
@@ -296,6 +313,11 @@ def main(argv=None):
     print("cases %d, failed %d, skipped %d, matched pairs %d; keypoints %d, angles not bit-identical %d (max %.3g deg), "
           "descriptors differing %d of %d" % (case, nfail, nskip, nmatch, stats["kp_total"], stats["angle_inexact"],
                                              stats["angle_max_deg"], stats["desc_diff"], stats["desc_total"]), flush=True)
+    print("quadtree size ties straddling the cut (the reference orders them by heap address): %d of %d frames, %d levels; "
+          "keypoints that change with the tie order (earliest- instead of latest-created node first, sampled): %d of %d"
+          % (stats["tie_frames"], stats["frames"], stats["tie_levels"], stats["tie_dependent_kp"], stats["tie_sampled_kp"]), flush=True)
+    if stats_out is not None:
+        stats_out.update(stats)
     return 1 if nfail else 0
 
 

@@ -3,7 +3,7 @@
 # usage (inside gpurun): bash tools/prof.sh <tag> [bench args]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --cpu-frames 0 "$@" > gpurun_out/bench_prof_$tag.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu "$@" > gpurun_out/bench_prof_$tag.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, sys
 tag = sys.argv[1]
