@@ -172,7 +172,10 @@ struct orbgpu_extractor {
     bool graph_broken = false;  // capture failed once: plain launches from then on
     DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab, cell_tab, blur_tab;
     int blur_tiles = 0;
-    DevBuf st_img, st_kps, st_desc, st_counts;  // staging for the host entry points
+    // staging for the host entry points: images; and one block for keypoints | descriptors | counts | status word, so
+    // that a small call brings everything back with one copy
+    DevBuf st_img, st_out;
+    int32_t *status_cur = nullptr;  // the status word of the call in flight (status.p, or the one inside st_out)
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
     // chunked host batches: uploads and downloads on their own streams beside the kernels
@@ -375,9 +378,7 @@ static int ensure_buffers(orbgpu_extractor *e, const Geom &G, int batch, int img
     ENS(cand_count, B * ORBGPU_MAX_LEVELS * 4);
     ENS(status, 64);
     ENS(st_img, B * (size_t)img_w * img_h);
-    ENS(st_kps, B * (size_t)G.total_kp_cap * sizeof(orbgpu_keypoint));
-    ENS(st_desc, B * (size_t)G.total_kp_cap * 32);
-    ENS(st_counts, B * 4);
+    ENS(st_out, B * (size_t)G.total_kp_cap * (sizeof(orbgpu_keypoint) + 32) + B * 4 + 64);
 #undef ENS
     // pinned staging: outputs (keypoints, descriptors, counts, status) followed by the input images
     const size_t pin = B * (size_t)G.total_kp_cap * (sizeof(orbgpu_keypoint) + 32) + B * 4 + 64 + B * (size_t)img_w * img_h;
@@ -556,7 +557,7 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drop_graph(e);
     DevBuf *bufs[] = {&e->pyr, &e->blur, &e->slots, &e->cell_counts, &e->cand, &e->nodes, &e->scratch, &e->sel, &e->sel_count,
-                      &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->cell_tab, &e->blur_tab, &e->st_img, &e->st_kps, &e->st_desc, &e->st_counts};
+                      &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->cell_tab, &e->blur_tab, &e->st_img, &e->st_out};
     for (DevBuf *b : bufs) b->release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
@@ -590,7 +591,7 @@ int orbgpu_extractor_status(orbgpu_extractor *e, int32_t *flags)
     if (!e || !flags) return ORBGPU_E_INVALID;
     ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
-    ORBGPU_HIP_CHECK(hipMemcpy(flags, e->status.p, 4, hipMemcpyDeviceToHost));
+    ORBGPU_HIP_CHECK(hipMemcpy(flags, e->status_cur ? e->status_cur : (int32_t *)e->status.p, 4, hipMemcpyDeviceToHost));
     return ORBGPU_OK;
 }
 
@@ -701,6 +702,7 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_imgs, int3
     ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
     int rc = set_geometry(e, w, h);
     if (rc) return rc;
+    e->status_cur = (int32_t *)e->status.p;
     return enqueue_extract(e, 0, d_imgs, nimg, stride, frame_stride, d_kps, d_desc, capacity, d_counts, true);
 }
 
@@ -726,7 +728,8 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     }
 #define STAGE_MARK(i) do { if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[i], st)); } while (0)
     // the status word describes one call alone (a captured sequence clears it on every replay as well)
-    if (clear_status) ORBGPU_HIP_CHECK(hipMemsetAsync(e->status.p, 0, 4, st));
+    int32_t *status = e->status_cur;
+    if (clear_status) ORBGPU_HIP_CHECK(hipMemsetAsync(status, 0, 4, st));
     STAGE_MARK(0);
     if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, pyr, G, (const XTab *)e->xtab.p, (const YTab *)e->ytab.p)))
         return rc;
@@ -744,12 +747,12 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     if ((rc = launch_blur(ax, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
     if (!e->serialize) ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
-    if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, (int32_t *)e->status.p)))
+    if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status)))
         return rc;
     STAGE_MARK(3);
     if (!e->serialize) ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
     if ((rc = launch_describe(st, nimg, pyr, blur, G, sel, sel_count, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts, capacity,
-                              (int32_t *)e->status.p)))
+                              status)))
         return rc;
     STAGE_MARK(4);
 #undef STAGE_MARK
@@ -808,8 +811,12 @@ static int extract_batch_chunked(orbgpu_extractor *e, const uint8_t *const *imgs
     int32_t *h_status = h_counts + e->p.max_batch;
     uint8_t *h_in = (uint8_t *)(h_status + 16);
     hipStream_t st = e->stream;
+    e->status_cur = (int32_t *)e->status.p;
     ORBGPU_HIP_CHECK(hipMemsetAsync(e->status.p, 0, 4, st));
     int rc = ORBGPU_OK;
+    orbgpu_keypoint *st_kps = (orbgpu_keypoint *)e->st_out.p;
+    uint8_t *st_desc = (uint8_t *)(st_kps + (size_t)e->p.max_batch * cap);
+    int32_t *st_counts = (int32_t *)(st_desc + (size_t)e->p.max_batch * cap * 32);
 
     auto stage_in = [&](int c) {  // pageable frames of chunk c -> pinned
         const int f0 = c * chunk, n = std::min(chunk, nimg - f0);
@@ -845,9 +852,9 @@ static int extract_batch_chunked(orbgpu_extractor *e, const uint8_t *const *imgs
         const int f0 = c * chunk, n = std::min(chunk, nimg - f0);
         hipEvent_t ev_up = e->chunk_ev[3 * c], ev_done = e->chunk_ev[3 * c + 1], ev_down = e->chunk_ev[3 * c + 2];
         uint8_t *d_img = (uint8_t *)e->st_img.p + (size_t)f0 * fbytes;
-        orbgpu_keypoint *d_k = (orbgpu_keypoint *)e->st_kps.p + (size_t)f0 * cap;
-        uint8_t *d_d = (uint8_t *)e->st_desc.p + (size_t)f0 * cap * 32;
-        int32_t *d_c = (int32_t *)e->st_counts.p + f0;
+        orbgpu_keypoint *d_k = st_kps + (size_t)f0 * cap;
+        uint8_t *d_d = st_desc + (size_t)f0 * cap * 32;
+        int32_t *d_c = st_counts + f0;
         ORBGPU_HIP_CHECK(hipMemcpyAsync(d_img, in_pinned ? imgs[f0] : h_in + (size_t)f0 * fbytes, (size_t)n * fbytes, hipMemcpyHostToDevice,
                                         e->up_stream));
         ORBGPU_HIP_CHECK(hipEventRecord(ev_up, e->up_stream));
@@ -914,15 +921,17 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
     int32_t *h_status = h_counts + nimg;
     // upload, extraction, downloads: every address involved belongs to the handle, so the sequence is the same for
     // every call with this geometry and batch size
+    // device block of this call, laid out like the pinned one: keypoints | descriptors | counts | status word
+    orbgpu_keypoint *d_k = (orbgpu_keypoint *)e->st_out.p;
+    uint8_t *d_d = (uint8_t *)(d_k + (size_t)nimg * cap);
+    int32_t *d_c = (int32_t *)(d_d + (size_t)nimg * cap * 32);
+    e->status_cur = d_c + nimg;
+    const size_t block_bytes = (size_t)nimg * cap * (sizeof(orbgpu_keypoint) + 32) + (size_t)nimg * 4 + 4;
     auto enqueue = [&]() -> int {
         ORBGPU_HIP_CHECK(hipMemcpyAsync(e->st_img.p, h_in, (size_t)nimg * w * h, hipMemcpyHostToDevice, st));
-        int r = orbgpu_extract_batch_device(e, (const uint8_t *)e->st_img.p, nimg, w, h, w, (size_t)w * h,
-                                            (orbgpu_keypoint *)e->st_kps.p, (uint8_t *)e->st_desc.p, cap, (int32_t *)e->st_counts.p);
+        int r = enqueue_extract(e, 0, (const uint8_t *)e->st_img.p, nimg, w, (size_t)w * h, d_k, d_d, cap, d_c, true);
         if (r) return r;
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(h_kps, e->st_kps.p, (size_t)nimg * cap * sizeof(orbgpu_keypoint), hipMemcpyDeviceToHost, st));
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(h_desc, e->st_desc.p, (size_t)nimg * cap * 32, hipMemcpyDeviceToHost, st));
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(h_counts, e->st_counts.p, (size_t)nimg * 4, hipMemcpyDeviceToHost, st));
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(h_status, e->status.p, 4, hipMemcpyDeviceToHost, st));
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(hp, d_k, block_bytes, hipMemcpyDeviceToHost, st));
         return ORBGPU_OK;
     };
     const bool want_graph = !e->profile && !e->graph_broken && nimg <= kGraphMaxFrames;
