@@ -713,7 +713,9 @@ __device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__re
 {
     // dynamic LDS: keys_cap 64-bit sort keys, then (lds_nodes != 0) the node
     // arrays and per-node work lists of this level -- keeping them on chip takes
-    // a dozen dependent global-memory round trips out of every subdivision round
+    // a dozen dependent global-memory round trips out of every subdivision round.
+    // keys_cap == 0: the level holds more nodes than LDS has room for sort keys (more than 4092 features on a
+    // level); the keys then live behind the level's work lists in global memory.
     extern __shared__ __align__(16) unsigned char dyn_lds[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(dyn_lds);
     int *coff = reinterpret_cast<int *>(dyn_lds + dyn_coff_off);  // blockDim.x + 1 cell offsets of the gather
@@ -729,7 +731,8 @@ __device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__re
     c.buf1 = c.buf0 + g.cand_cap;
     c.nl0 = nodes + (int64_t)f * G.node_frame + g.node_off;
     c.nl1 = c.nl0 + g.node_cap;
-    int32_t *scr = scratch + ((int64_t)f * G.node_frame + g.node_off) * 4;
+    int32_t *scr = scratch + ((int64_t)f * G.node_frame + g.node_off) * kScratchPerNode;  // 12 * node_cap words
+    if (keys_cap == 0) keys = reinterpret_cast<unsigned long long *>(scr + 8 * g.node_cap);  // 2 * node_cap keys
     c.S = scr;
     c.cnt4 = scr + g.node_cap;
     c.cbase = scr + 5 * g.node_cap;
@@ -1461,9 +1464,10 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     int maxcap = 0;
     for (int l = 0; l < G.nlevels; l++) maxcap = G.lv[l].node_cap > maxcap ? G.lv[l].node_cap : maxcap;
     int keys_cap = 2;
-    while (keys_cap < maxcap) keys_cap <<= 1;
+    while (keys_cap < maxcap) keys_cap <<= 1;  // the bitonic sort pads to a power of two: < 2 * node_cap keys
+    if (keys_cap > 4096) keys_cap = 0;         // no room in LDS: the keys go to the level's global scratch
     const size_t node_bytes = (size_t)maxcap * (2 * sizeof(QNode) + 8 * sizeof(int32_t));
-    const int lds_nodes = (size_t)keys_cap * 8 + node_bytes <= 56 * 1024;
+    const int lds_nodes = keys_cap && (size_t)keys_cap * 8 + node_bytes <= 56 * 1024;
     // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several
     const int threads = nimg * G.nlevels >= 256 ? 256 : 1024;
     const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);

@@ -275,8 +275,8 @@ static int build_geometry(const orbgpu_extractor *e, int w, int h, Geom *G, std:
         g.hX = width / (float)g.nIni;
         int nc = g.quota + 3 > 4 * g.nIni ? g.quota + 3 : 4 * g.nIni;
         g.node_cap = (int32_t)align_up(nc + 1, 4);
-        if (g.node_cap > 4096) {
-            set_error("level %d: %d features exceed the quadtree capacity of 4092 per level", l, g.quota);
+if (g.node_cap > (1 << 20)) {
+            set_error("level %d: %d features exceed the quadtree capacity of 2^20 per level", l, g.quota);
             return ORBGPU_E_UNSUPPORTED;
         }
         g.node_off = node;
@@ -372,7 +372,7 @@ static int ensure_buffers(orbgpu_extractor *e, const Geom &G, int batch, int img
     ENS(cell_counts, B * (size_t)G.total_cells * 4);
     ENS(cand, B * (size_t)G.cand_frame_u32 * 4);
     ENS(nodes, B * (size_t)G.node_frame * sizeof(QNode));
-    ENS(scratch, B * (size_t)G.node_frame * 4 * sizeof(int32_t));
+    ENS(scratch, B * (size_t)G.node_frame * kScratchPerNode * sizeof(int32_t));
     ENS(sel, B * (size_t)G.total_kp_cap * 4);
     ENS(sel_count, B * ORBGPU_MAX_LEVELS * 4);
     ENS(cand_count, B * ORBGPU_MAX_LEVELS * 4);
@@ -717,7 +717,7 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     uint32_t *slots = (uint32_t *)e->slots.p + f0 * (size_t)G.slot_frame_u32, *cand = (uint32_t *)e->cand.p + f0 * (size_t)G.cand_frame_u32;
     int32_t *cell_counts = (int32_t *)e->cell_counts.p + f0 * (size_t)G.total_cells;
     QNode *nodes = (QNode *)e->nodes.p + f0 * (size_t)G.node_frame;
-    int32_t *scratch = (int32_t *)e->scratch.p + f0 * (size_t)G.node_frame * 4;
+    int32_t *scratch = (int32_t *)e->scratch.p + f0 * (size_t)G.node_frame * kScratchPerNode;
     uint32_t *sel = (uint32_t *)e->sel.p + f0 * (size_t)G.total_kp_cap;
     int32_t *sel_count = (int32_t *)e->sel_count.p + f0 * (size_t)G.nlevels, *cand_count = (int32_t *)e->cand_count.p + f0 * (size_t)G.nlevels;
     hipEvent_t *ev = nullptr;

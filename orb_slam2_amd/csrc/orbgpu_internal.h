@@ -11,7 +11,8 @@ namespace orbgpu {
 constexpr int kEdge = 19;        // EDGE_THRESHOLD: halo kept around every pyramid level
 constexpr int kLeftMargin = 32;  // bytes in front of each interior row (>= kEdge, keeps rows 32 B aligned)
 constexpr int kMinBorder = 16;   // EDGE_THRESHOLD - 3: origin of the FAST search area
-constexpr int kMaxRoots = 16;    // initial quadtree nodes (round(width/height))
+constexpr int kMaxRoots = 128;   // initial quadtree nodes (round(width/height)): the widest strip of the smallest level
+constexpr int kScratchPerNode = 6;  // int32 words of quadtree scratch per entry of a level's two node lists (see octree_level)
 constexpr int kMaxTile = 66;     // largest FAST cell incl. 3 px apron (cells are < 60 px)
 constexpr int kRW = 128, kRH = 32;  // output tile of one resize workgroup
 

@@ -480,3 +480,23 @@ def test_mono_init_extractor_in_a_batch(oracle):
         assert int((desc != odesc).any(axis=1).sum()) <= 0.001 * len(desc)
     k1, d1 = ex(seq[3])
     assert np.array_equal(res[3][0], k1) and np.array_equal(res[3][1], d1)
+
+
+def test_many_roots_and_many_features_per_level(oracle):
+    """Shapes beyond the on-chip quadtree storage: a strip whose search area is 37 times as wide as it is high (37
+    root nodes, src/ORBextractor.cc:696) and a level quota above 4092 features (sort keys in global memory)."""
+    rng = np.random.default_rng(3)
+    strip = rng.integers(0, 256, (80, 2000), dtype=np.uint8)  # white noise: corners everywhere
+    from orb_slam2_amd.api import ORBextractor
+    ex = ORBextractor(1500, 1.2, 2, 20, 7, max_width=2000, max_height=80)
+    _compare(ex, oracle.Extractor(1500, 1.2, 2, 20, 7), strip)
+    big = synth.sequence(1920, 1080, 1, seed=6, n_shapes=40000)[0]
+    big = (big.astype(np.int16) + rng.integers(-12, 13, big.shape)).clip(0, 255).astype(np.uint8)
+    ex = ORBextractor(25000, 1.2, 8, 12, 5, max_width=1920, max_height=1080)
+    assert ex.mnFeaturesPerLevel[0] > 4092
+    kps, desc = ex(big)
+    okps, odesc = oracle.Extractor(25000, 1.2, 8, 12, 5).extract(big)
+    assert len(kps) == len(okps) and (kps["octave"] == 0).sum() > 4092
+    for f in ("x", "y", "size", "response", "octave"):
+        assert np.array_equal(kps[f], okps[f]), f
+    assert int((desc != odesc).any(axis=1).sum()) <= 0.001 * len(desc)
