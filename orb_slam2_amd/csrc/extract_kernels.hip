@@ -7,6 +7,8 @@
 // Reference lines are relative to /root/reference/src/ORB_SLAM2/.
 #include <vector>
 
+#include <stdlib.h>
+
 #include "orbgpu_internal.h"
 
 namespace orbgpu {
@@ -190,13 +192,17 @@ constexpr int kStampWgs = 1 << 19;
 __device__ unsigned g_fast_stamps[8 * kStampWgs];
 #endif
 constexpr int kFastThreads = 128;  // threads of a FAST workgroup
-constexpr int kTP = 72;  // LDS tile pitch in bytes (18 dwords: one lead byte + a 66 px row, rounded up)
+// LDS tile pitch in bytes, a template parameter of the FAST kernels: 72 (18 dwords: one lead byte + a 66 px row, rounded
+// up) holds every cell the reference can make; 48 holds cell images up to 44 px wide (grids of ~30 px cells on levels
+// wider than a few cells, the usual case) in two thirds of the LDS and of the copy's instructions.
+constexpr int kTPWide = 72, kTPNarrow = 48;
 
 // Strength A of the best 9-long arc: max over the 16 arcs of the minimum
 // signed contrast, both polarities.  A pixel is a FAST corner at threshold t
 // iff A > t, and cv::FAST's response is then A-1.  Both polarities run in one
 // packed 16-bit min chain on (v - p, p - v).
 typedef short short2v __attribute__((ext_vector_type(2)));
+template <int kTP>
 __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
 {
     const int v = c[0];
@@ -270,25 +276,30 @@ typedef __attribute__((address_space(3))) void fast_lvoid;
 // the builtin, the compiler orders every later LDS write and atomic of the wave behind them (it cannot see that
 // they go to the other buffer), which would stall the wave until the copy has landed.  The caller therefore
 // waits itself (fast_stage_wait) before the barrier that precedes the first read of the buffer.
-__device__ __forceinline__ void fast_stage_cell(const FastCell &c, uint8_t *buf, int wave, int lane)
+template <int kTP>
+__device__ __forceinline__ void fast_stage_cell(const FastCell &c, uint8_t *buf, int wave, int lane, int nwaves)
 {
-    const int npieces = (c.ch * (kTP / 4) + 63) >> 6;
+    constexpr int RP = kTP / 4;
+    constexpr int kRecip = (65536 + RP - 1) / RP;  // d / RP = d * kRecip >> 16 for the d < 2^13 of a tile
+    const int npieces = (c.ch * RP + 63) >> 6;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(fast_lvoid *)buf;
-    for (int p = wave; p < npieces; p += kFastThreads / 64) {
+    const uint8_t *src = c.src;  // uniform: the loads take it as their scalar base and a 32-bit lane offset
+    for (int p = wave; p < npieces; p += nwaves) {
         const int d = (p << 6) + lane;
-        const int row = (d * 3641) >> 16;  // d / 18 for d < 2^15
-        const int col = d - row * (kTP / 4);
-        const uint8_t *gp = c.src + (uint32_t)min(row, c.ch - 1) * (uint32_t)c.pitch + 4u * (uint32_t)min(col, c.ndw - 1);
+        const int row = (d * kRecip) >> 16;
+        const int col = d - row * RP;
+        const uint32_t off = (uint32_t)min(row, c.ch - 1) * (uint32_t)c.pitch + 4u * (uint32_t)min(col, c.ndw - 1);
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + ((uint32_t)p << 8));
         uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(gp), "s"(dst)
+                     : "v"(off), "s"(src), "s"(dst)
                      : "memory");
     }
 }
 __device__ __forceinline__ void fast_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+template <int kTP>
 __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G, const uint32_t *__restrict__ cell_tab,
                                                     uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts,
                                                     int cells_per_wg, int lds_tile_bytes, int lds_score_off, int lds_maxima_off,
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     const int cell0 = blockIdx.x * cells_per_wg;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     FastCell nx = fast_cell_info(pyr, G, cell_tab, f, cell0);
-    if (nx.state == 2) fast_stage_cell(nx, tile, wave, lane);
+    if (nx.state == 2) fast_stage_cell<kTP>(nx, tile, wave, lane, kFastThreads / 64);
 #pragma unroll 1
     for (int k = 0; k < cells_per_wg; k++) {
         const FastCell cu = nx;
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
         if (cu.state == 1) {
             if (tid == 0) *cnt_out = 0;
             // the other buffer was last read before the barrier that ended the previous cell
-            if (nx.state == 2) fast_stage_cell(nx, nxt, wave, lane);
+            if (nx.state == 2) fast_stage_cell<kTP>(nx, nxt, wave, lane, kFastThreads / 64);
             continue;
         }
         const int wi = cu.cw - 6, hi = cu.ch - 6;
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     fast_stage_wait();  // the first cell's copy (later cells were waited for below)
     __syncthreads();
     ORB_STAMP(1);
-    if (nx.state == 2) fast_stage_cell(nx, nxt, wave, lane);  // lands during the rejection stage
+    if (nx.state == 2) fast_stage_cell<kTP>(nx, nxt, wave, lane, kFastThreads / 64);  // lands during the rejection stage
 
     // stage 1: cheap rejection at the lower threshold, four horizontally adjacent pixels per lane: any 9-long
     // arc contains one pixel of each opposite pair (k, k+8), so a corner needs the brighter of every even pair
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     for (int q = tid; q < nq; q += kFastThreads) {
         const int i = queue[q];
         const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
-        const int A = fast_arc_strength(t0 + (y + 3) * kTP + (x + 3));
+        const int A = fast_arc_strength<kTP>(t0 + (y + 3) * kTP + (x + 3));
         if (A > t) score[(y + 1) * kTP + (x + 1)] = (uint8_t)(A - 1);
     }
     __syncthreads();
@@ -1445,6 +1456,8 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
         wmax = G.lv[l].wCell > wmax ? G.lv[l].wCell : wmax;
         hmax = G.lv[l].hCell > hmax ? G.lv[l].hCell : hmax;
     }
+    // a tile row holds the cell image (cell + 6) behind one lead byte, in whole dwords
+    const int kTP = wmax + 6 + 4 <= kTPNarrow ? kTPNarrow : kTPWide;
     const int tile_bytes = ((hmax + 6) * kTP + 255) & ~255;  // whole 64-dword pieces of the direct global -> LDS copy
     const int score_off = 2 * tile_bytes, maxima_off = score_off + (((hmax + 2) * kTP + 15) & ~15);
     const int queue_off = maxima_off + ((((wmax + 1) / 2) * ((hmax + 1) / 2) * 4 + 15) & ~15);
@@ -1452,8 +1465,13 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
     // runs of cells per workgroup hide the staging latency when there are many more workgroups than the chip
     // holds at once; with a few frames the cells are better spread over all CUs
     const int per_wg = (int64_t)G.total_cells * nimg >= 16384 ? kFastQuad : 1;
-    hipLaunchKernelGGL(k_fast_cells, dim3((G.total_cells + per_wg - 1) / per_wg, nimg), dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots,
-                       cell_counts, per_wg, tile_bytes, score_off, maxima_off, queue_off);
+    const dim3 grid((G.total_cells + per_wg - 1) / per_wg, nimg);
+    if (kTP == kTPNarrow)
+        hipLaunchKernelGGL(k_fast_cells<kTPNarrow>, grid, dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots, cell_counts, per_wg, tile_bytes,
+                           score_off, maxima_off, queue_off);
+    else
+        hipLaunchKernelGGL(k_fast_cells<kTPWide>, grid, dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots, cell_counts, per_wg, tile_bytes,
+                           score_off, maxima_off, queue_off);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
