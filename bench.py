@@ -269,12 +269,19 @@ def cpp_latency(frames):
         path = f.name
     try:
         r = subprocess.run([exe, path], capture_output=True, text=True, timeout=120)
+        out = None
         for line in r.stdout.splitlines():
             t = line.split()
             if t and t[0] == "latency":
-                return {"extract_ms": float(t[2]), "stack_matcher_search_ms": float(t[4]), "matcher_ctor_us": float(t[6]),
-                        "note": "C++ ORBextractor::operator() and an ORBmatcher built on the stack + SearchForInitialization per "
-                                "frame (include/ORBextractor.h, include/ORBmatcher.h), host pointers in and out, median of 50"}
+                out = {"extract_ms": float(t[2]), "stack_matcher_search_ms": float(t[4]), "matcher_ctor_us": float(t[6]),
+                       "note": "C++ ORBextractor::operator() and an ORBmatcher built on the stack + SearchForInitialization per "
+                               "frame (include/ORBextractor.h, include/ORBmatcher.h), host pointers in and out, median of 50; "
+                               "device_frame_*: the same two steps with DeviceFrame (include/FrameDevice.h: extraction + "
+                               "undistortion + grid kept on the GPU, mvKeysUn fetched; the search reads both frames there)"}
+            if t and t[0] == "device_frames" and out is not None:
+                out["device_frame_build_ms"] = float(t[2])
+                out["device_frame_matcher_search_ms"] = float(t[4])
+        return out
     except Exception:
         return None
     finally:

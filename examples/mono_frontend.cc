@@ -12,9 +12,21 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <memory>
+
+#include "FrameDevice.h"
 #include "ORBVocabulary.h"
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+
+// What a Frame has to carry for ORBmatcher::SearchForInitialization(Frame&, Frame&, ...) when its arrays stay on the
+// GPU: the undistorted keypoints on the host (the caller reads their positions), the bounds, and the device copy.
+struct MiniFrame {
+    std::vector<orbcv::KeyPoint> mvKeysUn;
+    orbcv::Mat mDescriptors;  // stays empty: the descriptors are read on the device
+    float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
+    std::shared_ptr<ORB_SLAM2::DeviceFrame> mpDeviceFrame;
+};
 
 int main(int argc, char **argv)
 {
@@ -91,5 +103,38 @@ int main(int argc, char **argv)
     }
     std::sort(te.begin(), te.end()); std::sort(tm.begin(), tm.end()); std::sort(tc.begin(), tc.end());
     std::printf("latency extract_ms %.4f stack_matcher_ms %.4f matcher_ctor_us %.2f\n", te[te.size() / 2], tm[tm.size() / 2], tc[tc.size() / 2]);
+
+    // The same two steps with device-resident frames: the constructor part of Frame (extraction, undistortion, grid;
+    // src/Frame.cc:175-226) leaves everything on the GPU and fetches mvKeysUn only, and the search reads both frames there.
+    const float K4[4] = {517.3f, 516.5f, 318.6f, 255.3f}, D5[5] = {0, 0, 0, 0, 0};
+    MiniFrame fr[2];
+    for (int i = 0; i < 2; i++) {
+        fr[i].mpDeviceFrame = std::make_shared<ORB_SLAM2::DeviceFrame>(extractor.MaxKeypoints());
+        fr[i].mnMaxX = (float)w; fr[i].mnMaxY = (float)h;
+    }
+    std::vector<double> tb, ts;
+    for (int it = 0; it < 55; it++) {
+        MiniFrame &F = fr[it & 1];
+        const clk::time_point t0 = clk::now();
+        const int N = F.mpDeviceFrame->BuildMono(extractor, im[it & 1].data, w, h, w, K4, D5, bounds);
+        F.mpDeviceFrame->KeysUn(F.mvKeysUn);
+        const clk::time_point t1 = clk::now();
+        if (N != (int)keys[it & 1].size()) { std::fprintf(stderr, "device frame: %d keypoints, operator() %zu (%s)\n", N, keys[it & 1].size(), F.mpDeviceFrame->LastError().c_str()); return 1; }
+        if (it == 0) continue;  // the other frame is not built yet
+        int nm;
+        {
+            ORB_SLAM2::ORBmatcher onStack(0.9f, true);
+            for (size_t i = 0; i < fr[0].mvKeysUn.size(); i++) prev[i] = fr[0].mvKeysUn[i].pt;
+            nm = onStack.SearchForInitialization(fr[0], fr[1], prev, matches12, 100);
+        }
+        const clk::time_point t2 = clk::now();
+        if (nm != n) { std::fprintf(stderr, "device frames: %d matches, arrays %d\n", nm, n); return 1; }
+        if (it >= 5) {
+            tb.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+            ts.push_back(std::chrono::duration<double, std::milli>(t2 - t1).count());
+        }
+    }
+    std::sort(tb.begin(), tb.end()); std::sort(ts.begin(), ts.end());
+    std::printf("device_frames build_ms %.4f stack_matcher_ms %.4f\n", tb[tb.size() / 2], ts[ts.size() / 2]);
     return 0;
 }

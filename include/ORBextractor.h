@@ -70,11 +70,13 @@ public:
     orbcv::Mat &operator[](size_t level) { fetch(level); return levels_[level]; }
     const orbcv::Mat &operator[](size_t level) const { fetch(level); return levels_[level]; }
     orbcv::Mat &at(size_t level) { fetch(level); return levels_.at(level); }
+    // the handle has extracted another image: host copies of its levels are stale (every caller of an extract entry
+    // point of the C ABI on Handle() says so here; operator() does it itself)
+    void Invalidate() { fresh_.assign(fresh_.size(), 0); }
 
 private:
     friend class ORBextractor;
     void bind(orbgpu_extractor *h, int nlevels) { handle_ = h; levels_.resize((size_t)nlevels); fresh_.assign((size_t)nlevels, 0); }
-    void invalidate() { fresh_.assign(fresh_.size(), 0); }
     void fetch(size_t l) const
     {
         if (!handle_ || l >= levels_.size() || fresh_[l]) return;
@@ -153,7 +155,7 @@ public:
         if (n == 0) descriptors.release();
         else { descriptors.create(n, 32); std::memcpy(descriptors.data, desc_buf_.data(), (size_t)n * 32); }
 #endif
-        mvImagePyramid.invalidate();  // levels are copied from the device when somebody reads them
+        mvImagePyramid.Invalidate();  // levels are copied from the device when somebody reads them
     }
 
     // reference: include/ORBextractor.h:63-83
@@ -166,7 +168,8 @@ public:
 
     ImagePyramidMirror mvImagePyramid;  // include/ORBextractor.h:85; read as mvImagePyramid[level]
 
-    orbgpu_extractor *Handle() { return handle_; }  // for ORBmatcher::ComputeStereoMatches
+    orbgpu_extractor *Handle() { return handle_; }  // for ORBmatcher::ComputeStereoMatches and DeviceFrame
+    int MaxKeypoints() const { return max_kp_; }   // upper bound of keypoints per image: capacity of a DeviceFrame
     const std::string &LastError() const { return err_; }
 
 protected:

@@ -55,6 +55,16 @@ struct KeyFrameGridOrigin {
 
 namespace orbgpu_detail {
 
+/* A Frame / KeyFrame type that carries a device-resident copy of its arrays exposes it as a member
+ * `mpDeviceFrame`: anything whose `->Handle()` is the orbgpu_frame (a std::shared_ptr<DeviceFrame> of
+ * FrameDevice.h, or a plain pointer).  The searches then read the train side where it lies on the GPU; types
+ * without the member, and frames whose pointer is null, take the array entry points. */
+template <class F, class = void> struct HasDeviceFrame : std::false_type {};
+template <class F> struct HasDeviceFrame<F, decltype((void)std::declval<const F &>().mpDeviceFrame, void())> : std::true_type {};
+template <class F> inline const orbgpu_frame *device_frame(const F &f, std::true_type) { return f.mpDeviceFrame ? f.mpDeviceFrame->Handle() : nullptr; }
+template <class F> inline const orbgpu_frame *device_frame(const F &, std::false_type) { return nullptr; }
+template <class F> inline const orbgpu_frame *device_frame(const F &f) { return device_frame(f, HasDeviceFrame<F>()); }
+
 struct V3 { float x, y, z; };
 struct SE3 { float R[9]; float t[3]; };  // x_c = R x_w + t, R row-major
 
@@ -205,9 +215,12 @@ int ORBmatcher::SearchByProjection(FrameT &F, const std::vector<MapPointT *> &vp
     std::vector<uint8_t> tmp;
     std::vector<int32_t> assign((size_t)F.N, -1);
     int32_t nmatches = 0;
-    if (check(orbgpu_search_by_projection(handle_, ORBGPU_MODE_LOCAL_MAP, q.data(), qd.data(), (int32_t)q.size(),
-                                          D::as_keypoints(F.mvKeysUn), D::descriptor_block(F.mDescriptors, F.N, tmp), F.mvuRight.data(),
-                                          F.N, b, occ.data(), assign.data(), TH_HIGH, mfNNratio, 0, &nmatches)))
+    const orbgpu_frame *df = D::device_frame(F);
+    if (check(df ? orbgpu_search_by_projection_frame(handle_, ORBGPU_MODE_LOCAL_MAP, q.data(), qd.data(), (int32_t)q.size(), df, occ.data(),
+                                                     assign.data(), TH_HIGH, mfNNratio, 0, &nmatches)
+                 : orbgpu_search_by_projection(handle_, ORBGPU_MODE_LOCAL_MAP, q.data(), qd.data(), (int32_t)q.size(),
+                                               D::as_keypoints(F.mvKeysUn), D::descriptor_block(F.mDescriptors, F.N, tmp),
+                                               F.mvuRight.data(), F.N, b, occ.data(), assign.data(), TH_HIGH, mfNNratio, 0, &nmatches)))
         return 0;
     for (int t = 0; t < F.N; t++)
         if (assign[t] >= 0) F.mvpMapPoints[t] = vpMapPoints[qIndex[assign[t]]];  // :123
@@ -258,10 +271,13 @@ int ORBmatcher::SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame
     std::vector<uint8_t> tmp;
     std::vector<int32_t> assign((size_t)N2, -1);
     int32_t nmatches = 0;
-    if (check(orbgpu_search_by_projection(handle_, ORBGPU_MODE_LAST_FRAME, q.data(), qd.data(), (int32_t)q.size(),
-                                          D::as_keypoints(CurrentFrame.mvKeysUn), D::descriptor_block(CurrentFrame.mDescriptors, N2, tmp),
-                                          CurrentFrame.mvuRight.data(), N2, b, occ.data(), assign.data(), TH_HIGH, mfNNratio,
-                                          mbCheckOrientation ? 1 : 0, &nmatches)))
+    const orbgpu_frame *df = D::device_frame(CurrentFrame);
+    if (check(df ? orbgpu_search_by_projection_frame(handle_, ORBGPU_MODE_LAST_FRAME, q.data(), qd.data(), (int32_t)q.size(), df, occ.data(),
+                                                     assign.data(), TH_HIGH, mfNNratio, mbCheckOrientation ? 1 : 0, &nmatches)
+                 : orbgpu_search_by_projection(handle_, ORBGPU_MODE_LAST_FRAME, q.data(), qd.data(), (int32_t)q.size(),
+                                               D::as_keypoints(CurrentFrame.mvKeysUn),
+                                               D::descriptor_block(CurrentFrame.mDescriptors, N2, tmp), CurrentFrame.mvuRight.data(), N2, b,
+                                               occ.data(), assign.data(), TH_HIGH, mfNNratio, mbCheckOrientation ? 1 : 0, &nmatches)))
         return 0;
     for (int t = 0; t < N2; t++) {
         if (assign[t] >= 0) CurrentFrame.mvpMapPoints[t] = LastFrame.mvpMapPoints[qIndex[assign[t]]];  // :1479
@@ -310,10 +326,13 @@ int ORBmatcher::SearchByProjection(FrameT &CurrentFrame, KeyFrameT *pKF, const s
     std::vector<uint8_t> tmp;
     std::vector<int32_t> assign((size_t)N2, -1);
     int32_t nmatches = 0;
-    if (check(orbgpu_search_by_projection(handle_, ORBGPU_MODE_KEYFRAME, q.data(), qd.data(), (int32_t)q.size(),
-                                          D::as_keypoints(CurrentFrame.mvKeysUn), D::descriptor_block(CurrentFrame.mDescriptors, N2, tmp),
-                                          nullptr, N2, b, occ.data(), assign.data(), ORBdist, mfNNratio, mbCheckOrientation ? 1 : 0,
-                                          &nmatches)))
+    const orbgpu_frame *df = D::device_frame(CurrentFrame);
+    if (check(df ? orbgpu_search_by_projection_frame(handle_, ORBGPU_MODE_KEYFRAME, q.data(), qd.data(), (int32_t)q.size(), df, occ.data(),
+                                                     assign.data(), ORBdist, mfNNratio, mbCheckOrientation ? 1 : 0, &nmatches)
+                 : orbgpu_search_by_projection(handle_, ORBGPU_MODE_KEYFRAME, q.data(), qd.data(), (int32_t)q.size(),
+                                               D::as_keypoints(CurrentFrame.mvKeysUn),
+                                               D::descriptor_block(CurrentFrame.mDescriptors, N2, tmp), nullptr, N2, b, occ.data(),
+                                               assign.data(), ORBdist, mfNNratio, mbCheckOrientation ? 1 : 0, &nmatches)))
         return 0;
     for (int t = 0; t < N2; t++) {
         if (assign[t] >= 0) CurrentFrame.mvpMapPoints[t] = vpMPs[qIndex[assign[t]]];  // :1608
@@ -368,9 +387,12 @@ int ORBmatcher::SearchByProjection(KeyFrameT *pKF, MatT Scw, const std::vector<M
     std::vector<int32_t> assign((size_t)N2, -1);
     int32_t nmatches = 0;
     if (check(orbgpu_matcher_set_grid_geometry(handle_, g))) return 0;
-    if (check(orbgpu_search_by_projection(handle_, ORBGPU_MODE_KEYFRAME, q.data(), qd.data(), (int32_t)q.size(),
-                                          D::as_keypoints(pKF->mvKeysUn), D::descriptor_block(pKF->mDescriptors, N2, tmp), nullptr, N2, b,
-                                          occ.data(), assign.data(), TH_LOW, mfNNratio, 0, &nmatches)))
+    const orbgpu_frame *df = D::device_frame(*pKF);
+    if (check(df ? orbgpu_search_by_projection_frame(handle_, ORBGPU_MODE_KEYFRAME, q.data(), qd.data(), (int32_t)q.size(), df, occ.data(),
+                                                     assign.data(), TH_LOW, mfNNratio, 0, &nmatches)
+                 : orbgpu_search_by_projection(handle_, ORBGPU_MODE_KEYFRAME, q.data(), qd.data(), (int32_t)q.size(),
+                                               D::as_keypoints(pKF->mvKeysUn), D::descriptor_block(pKF->mDescriptors, N2, tmp), nullptr, N2,
+                                               b, occ.data(), assign.data(), TH_LOW, mfNNratio, 0, &nmatches)))
         return 0;
     for (int t = 0; t < N2; t++)
         if (assign[t] >= 0) vpMatched[t] = vpPoints[qIndex[assign[t]]];  // :396
@@ -401,10 +423,14 @@ ORBmatcher::SearchByBoW(KeyFrameT *pKF, FrameT &F, std::vector<MapPointT *> &vpM
     std::vector<int32_t> assign((size_t)F.N, -1), qmatch(q.size(), -1);
     int32_t nmatches = 0;
     // the rotation histogram compares with F.mvKeys (:238); keypoint angles do not change with undistortion
-    if (check(orbgpu_search_by_bow(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(F.mvKeys),
-                                   D::descriptor_block(F.mDescriptors, F.N, tmp), F.N, segStart.data(), segIndex.data(),
-                                   (int32_t)segStart.size() - 1, nullptr, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, assign.data(),
-                                   qmatch.data(), &nmatches)))
+    const orbgpu_frame *df = D::device_frame(F);
+    if (check(df ? orbgpu_search_by_bow_frame(handle_, q.data(), qd.data(), (int32_t)q.size(), df, segStart.data(), segIndex.data(),
+                                              (int32_t)segStart.size() - 1, nullptr, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0,
+                                              assign.data(), qmatch.data(), &nmatches)
+                 : orbgpu_search_by_bow(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(F.mvKeys),
+                                        D::descriptor_block(F.mDescriptors, F.N, tmp), F.N, segStart.data(), segIndex.data(),
+                                        (int32_t)segStart.size() - 1, nullptr, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, assign.data(),
+                                        qmatch.data(), &nmatches)))
         return 0;
     for (size_t k = 0; k < q.size(); k++)
         if (qmatch[k] >= 0) vpMapPointMatches[qmatch[k]] = vpMapPointsKF[qIndex[k]];  // :232
@@ -436,10 +462,14 @@ int ORBmatcher::SearchByBoW(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPoi
     std::vector<uint8_t> tmp;
     std::vector<int32_t> assign((size_t)N2, -1), qmatch(q.size(), -1);
     int32_t nmatches = 0;
-    if (check(orbgpu_search_by_bow(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(pKF2->mvKeysUn),
-                                   D::descriptor_block(pKF2->mDescriptors, N2, tmp), N2, segStart.data(), segIndex.data(),
-                                   (int32_t)segStart.size() - 1, excluded.data(), TH_LOW - 1 /* bestDist1 < TH_LOW, :649 */, mfNNratio,
-                                   mbCheckOrientation ? 1 : 0, assign.data(), qmatch.data(), &nmatches)))
+    const orbgpu_frame *df = D::device_frame(*pKF2);
+    if (check(df ? orbgpu_search_by_bow_frame(handle_, q.data(), qd.data(), (int32_t)q.size(), df, segStart.data(), segIndex.data(),
+                                              (int32_t)segStart.size() - 1, excluded.data(), TH_LOW - 1, mfNNratio,
+                                              mbCheckOrientation ? 1 : 0, assign.data(), qmatch.data(), &nmatches)
+                 : orbgpu_search_by_bow(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(pKF2->mvKeysUn),
+                                        D::descriptor_block(pKF2->mDescriptors, N2, tmp), N2, segStart.data(), segIndex.data(),
+                                        (int32_t)segStart.size() - 1, excluded.data(), TH_LOW - 1 /* bestDist1 < TH_LOW, :649 */,
+                                        mfNNratio, mbCheckOrientation ? 1 : 0, assign.data(), qmatch.data(), &nmatches)))
         return 0;
     for (size_t k = 0; k < q.size(); k++)
         if (qmatch[k] >= 0) vpMatches12[qIndex[k]] = vpMapPoints2[qmatch[k]];  // :653
@@ -460,10 +490,14 @@ int ORBmatcher::SearchForInitialization(FrameT &F1, FrameT &F2, std::vector<Poin
     const float b[4] = {(float)F2.mnMinX, (float)F2.mnMinY, (float)F2.mnMaxX, (float)F2.mnMaxY};
     std::vector<uint8_t> tmp1, tmp2;
     int32_t nmatches = 0;
-    if (check(orbgpu_search_for_initialization(handle_, D::as_keypoints(F1.mvKeysUn), D::descriptor_block(F1.mDescriptors, n1, tmp1), n1,
-                                               D::as_keypoints(F2.mvKeysUn), D::descriptor_block(F2.mDescriptors, n2, tmp2), n2, b,
-                                               prev.data(), vnMatches12.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0,
-                                               &nmatches)))
+    const orbgpu_frame *df1 = D::device_frame(F1), *df2 = D::device_frame(F2);
+    if (check(df1 && df2
+                  ? orbgpu_search_for_initialization_frames(handle_, df1, df2, prev.data(), vnMatches12.data(), windowSize, mfNNratio,
+                                                            mbCheckOrientation ? 1 : 0, &nmatches)
+                  : orbgpu_search_for_initialization(handle_, D::as_keypoints(F1.mvKeysUn), D::descriptor_block(F1.mDescriptors, n1, tmp1),
+                                                     n1, D::as_keypoints(F2.mvKeysUn), D::descriptor_block(F2.mDescriptors, n2, tmp2), n2,
+                                                     b, prev.data(), vnMatches12.data(), windowSize, mfNNratio,
+                                                     mbCheckOrientation ? 1 : 0, &nmatches)))
         return 0;
     for (int i = 0; i < n1; i++)
         if (vnMatches12[i] >= 0) vbPrevMatched[i] = F2.mvKeysUn[vnMatches12[i]].pt;  // :566-568
@@ -509,11 +543,18 @@ int ORBmatcher::SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT *pKF2, MatT F1
     std::vector<uint8_t> tmp;
     std::vector<int32_t> qmatch(q.size(), -1);
     int32_t nmatches = 0;
-    if (check(orbgpu_search_for_triangulation(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(pKF2->mvKeysUn),
-                                              D::descriptor_block(pKF2->mDescriptors, N2, tmp), pKF2->mvuRight.data(), N2, segStart.data(),
-                                              segIndex.data(), (int32_t)segStart.size() - 1, hasMapPoint2.data(), F, ex, ey,
-                                              pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(), (int32_t)pKF2->mvScaleFactors.size(),
-                                              bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, qmatch.data(), &nmatches)))
+    const orbgpu_frame *df = D::device_frame(*pKF2);
+    if (check(df ? orbgpu_search_for_triangulation_frame(handle_, q.data(), qd.data(), (int32_t)q.size(), df, 1, segStart.data(),
+                                                         segIndex.data(), (int32_t)segStart.size() - 1, hasMapPoint2.data(), F, ex, ey,
+                                                         pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(),
+                                                         (int32_t)pKF2->mvScaleFactors.size(), bOnlyStereo ? 1 : 0,
+                                                         mbCheckOrientation ? 1 : 0, qmatch.data(), &nmatches)
+                 : orbgpu_search_for_triangulation(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(pKF2->mvKeysUn),
+                                                   D::descriptor_block(pKF2->mDescriptors, N2, tmp), pKF2->mvuRight.data(), N2,
+                                                   segStart.data(), segIndex.data(), (int32_t)segStart.size() - 1, hasMapPoint2.data(), F,
+                                                   ex, ey, pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(),
+                                                   (int32_t)pKF2->mvScaleFactors.size(), bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0,
+                                                   qmatch.data(), &nmatches)))
         return 0;
     std::vector<int> vMatches12((size_t)N1, -1);
     for (size_t k = 0; k < q.size(); k++)
@@ -570,9 +611,13 @@ int ORBmatcher::Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints
     std::vector<int32_t> qmatch(q.size(), -1);
     int32_t found = 0;
     if (check(orbgpu_matcher_set_grid_geometry(handle_, g))) return 0;
-    if (check(orbgpu_search_in_area(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(pKF->mvKeysUn),
-                                    D::descriptor_block(pKF->mDescriptors, pKF->N, tmp), pKF->mvuRight.data(), pKF->N, b,
-                                    pKF->mvInvLevelSigma2.data(), (int32_t)pKF->mvInvLevelSigma2.size(), 1, TH_LOW, qmatch.data(), &found)))
+    const orbgpu_frame *df = D::device_frame(*pKF);  // its grid was built with the Frame's own bounds
+    if (check(df ? orbgpu_search_in_area_frame(handle_, q.data(), qd.data(), (int32_t)q.size(), df, pKF->mvInvLevelSigma2.data(),
+                                               (int32_t)pKF->mvInvLevelSigma2.size(), 1, TH_LOW, qmatch.data(), &found)
+                 : orbgpu_search_in_area(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(pKF->mvKeysUn),
+                                         D::descriptor_block(pKF->mDescriptors, pKF->N, tmp), pKF->mvuRight.data(), pKF->N, b,
+                                         pKF->mvInvLevelSigma2.data(), (int32_t)pKF->mvInvLevelSigma2.size(), 1, TH_LOW, qmatch.data(),
+                                         &found)))
         return 0;
     int nFused = 0;
     for (int i = 0; i < nMPs; i++) {  // :1003-1022
@@ -637,9 +682,11 @@ int ORBmatcher::Fuse(KeyFrameT *pKF, MatT Scw, const std::vector<MapPointT *> &v
     std::vector<int32_t> qmatch(q.size(), -1);
     int32_t found = 0;
     if (check(orbgpu_matcher_set_grid_geometry(handle_, g))) return 0;
-    if (check(orbgpu_search_in_area(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(pKF->mvKeysUn),
-                                    D::descriptor_block(pKF->mDescriptors, pKF->N, tmp), nullptr, pKF->N, b, nullptr, 0, 0, TH_LOW,
-                                    qmatch.data(), &found)))
+    const orbgpu_frame *df = D::device_frame(*pKF);
+    if (check(df ? orbgpu_search_in_area_frame(handle_, q.data(), qd.data(), (int32_t)q.size(), df, nullptr, 0, 0, TH_LOW, qmatch.data(), &found)
+                 : orbgpu_search_in_area(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(pKF->mvKeysUn),
+                                         D::descriptor_block(pKF->mDescriptors, pKF->N, tmp), nullptr, pKF->N, b, nullptr, 0, 0, TH_LOW,
+                                         qmatch.data(), &found)))
         return 0;
     int nFused = 0;
     for (size_t k = 0; k < q.size(); k++) {  // :1133-1147, in the order of vpPoints
@@ -723,9 +770,12 @@ int ORBmatcher::SearchBySim3(KeyFrameT *pKF1, KeyFrameT *pKF2, std::vector<MapPo
         int32_t found = 0;
         int rc = check(orbgpu_matcher_set_grid_geometry(handle_, g));
         if (rc) return rc;
-        rc = check(orbgpu_search_in_area(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(dst->mvKeysUn),
-                                         D::descriptor_block(dst->mDescriptors, dst->N, tmp), nullptr, dst->N, b, nullptr, 0, 0, TH_HIGH,
-                                         qmatch.data(), &found));
+        const orbgpu_frame *df = D::device_frame(*dst);
+        rc = check(df ? orbgpu_search_in_area_frame(handle_, q.data(), qd.data(), (int32_t)q.size(), df, nullptr, 0, 0, TH_HIGH, qmatch.data(),
+                                                    &found)
+                      : orbgpu_search_in_area(handle_, q.data(), qd.data(), (int32_t)q.size(), D::as_keypoints(dst->mvKeysUn),
+                                              D::descriptor_block(dst->mDescriptors, dst->N, tmp), nullptr, dst->N, b, nullptr, 0, 0,
+                                              TH_HIGH, qmatch.data(), &found));
         if (rc) return rc;
         for (size_t k = 0; k < q.size(); k++) vnMatch[qIndex[k]] = qmatch[k];
         return ORBGPU_OK;

@@ -397,6 +397,111 @@ int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extrac
                         int32_t nR, float bf, float b, float *uRight, float *depth,
                         int32_t *nvalid);
 
+/* ---- Frame: device-resident frame state ----------------------------------- */
+
+/* What the constructors of Frame compute directly after the extraction
+ * (src/Frame.cc:58-116 stereo, :119-172 RGB-D, :175-226 monocular), kept on the
+ * device: mvKeys, mvKeysUn, mDescriptors, mvuRight, mvDepth and the 64x48 mGrid.
+ * The build calls run UndistortKeyPoints (:517-558), ComputeStereoMatches
+ * (:600-774) or ComputeStereoFromRGBD (:777-798) and AssignFeaturesToGrid
+ * (:270-293) behind the extraction on the extractor's stream and wait once; the
+ * *_frame matcher entry points then read the frame where it lies, and the host
+ * fetches only what it asks for (orbgpu_frame_download, orbgpu_frame_grid).  A
+ * frame owns its buffers: it stays valid while the extractor goes on to the next
+ * image (Tracking keeps mLastFrame; a KeyFrame copies its Frame's arrays,
+ * src/KeyFrame.cc:37-52, and can keep the handle instead).  capacity >=
+ * orbgpu_extractor_max_keypoints of the extractors it will be built from. */
+typedef struct orbgpu_frame orbgpu_frame;
+int orbgpu_frame_create(int32_t device, int32_t capacity, orbgpu_frame **out);
+void orbgpu_frame_destroy(orbgpu_frame *f);
+
+/* Frame::Frame, monocular (src/Frame.cc:175-226): ExtractORB(0, imGray),
+ * UndistortKeyPoints, mvuRight = mvDepth = -1, AssignFeaturesToGrid.  K4 = {fx,
+ * fy, cx, cy}, dist5 = {k1, k2, p1, p2, k3} as for orbgpu_undistort_keypoints;
+ * bounds4 = {mnMinX, mnMinY, mnMaxX, mnMaxY} (ComputeImageBounds, :560-597,
+ * computed once per camera by the caller as the reference does).  *n_out = N. */
+int orbgpu_frame_build_mono(orbgpu_frame *f, orbgpu_extractor *e, const uint8_t *img, int32_t w,
+                            int32_t h, int32_t stride, const float *K4, const float *dist5,
+                            const float *bounds4, int32_t *n_out);
+/* Frame::Frame, RGB-D (src/Frame.cc:119-172): depth[h][depth_stride_floats] is
+ * imDepth (float, already scaled by mDepthMapFactor); bf = mbf. */
+int orbgpu_frame_build_rgbd(orbgpu_frame *f, orbgpu_extractor *e, const uint8_t *img, int32_t w,
+                            int32_t h, int32_t stride, const float *depth,
+                            int32_t depth_stride_floats, float bf, const float *K4,
+                            const float *dist5, const float *bounds4, int32_t *n_out);
+/* Frame::Frame, stereo (src/Frame.cc:58-116): the two extractions run side by side
+ * on the two handles' streams (two threads in the reference, :78-81), then
+ * ComputeStereoMatches with its row table, sub-pixel refinement and median-based
+ * outlier rejection all on the device.  The right image's keypoints stay in the
+ * right extractor's buffers (the reference keeps mvKeysRight only for this step).
+ * b = mb, bf = mbf; *nvalid_out (nullable) = left keypoints with a depth. */
+int orbgpu_frame_build_stereo(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_extractor *right,
+                              const uint8_t *imgL, const uint8_t *imgR, int32_t w, int32_t h,
+                              int32_t stride, float bf, float b, const float *K4,
+                              const float *dist5, const float *bounds4, int32_t *n_out,
+                              int32_t *nvalid_out);
+
+/* A frame from host arrays (a Frame the program computed itself, a KeyFrame read
+ * back from a saved map): kps may be NULL (then = kps_un), uright / depth may be
+ * NULL (then -1: monocular); octaves must lie in 0 .. nlevels-1.  The grid is built
+ * over bounds4 as AssignFeaturesToGrid does (src/Frame.cc:270-293). */
+int orbgpu_frame_upload(orbgpu_frame *f, const orbgpu_keypoint *kps, const orbgpu_keypoint *kps_un,
+                        const uint8_t *desc, const float *uright, const float *depth, int32_t n,
+                        int32_t nlevels, const float *bounds4);
+
+/* N, the number of keypoints with a stereo / depth measurement, and the capacity.
+ * Any pointer may be NULL. */
+int orbgpu_frame_size(const orbgpu_frame *f, int32_t *n, int32_t *nvalid, int32_t *capacity);
+/* Host copies of mvKeys, mvKeysUn, mDescriptors, mvuRight, mvDepth (N entries
+ * each; any pointer may be NULL). */
+int orbgpu_frame_download(orbgpu_frame *f, orbgpu_keypoint *kps, orbgpu_keypoint *kps_un,
+                          uint8_t *desc, float *uright, float *depth);
+/* mGrid as CSR, laid out as orbgpu_assign_features_to_grid returns it. */
+int orbgpu_frame_grid(orbgpu_frame *f, int32_t *cell_start, int32_t *cell_index,
+                      int32_t *n_in_grid);
+/* Device views (valid until the frame is rebuilt or destroyed); d_count[0] = N. */
+int orbgpu_frame_device(const orbgpu_frame *f, const orbgpu_keypoint **d_kps,
+                        const orbgpu_keypoint **d_kps_un, const uint8_t **d_desc,
+                        const float **d_uright, const float **d_depth, const int32_t **d_count);
+
+/* The matcher entry points above with a frame as the train side: its undistorted
+ * keypoints, descriptors, uRight, bounds and grid are used where they lie, nothing
+ * of the train side is uploaded and no grid is built.  Arguments, semantics and
+ * outputs are those of the array versions (assign[N], qmatch[nq]).  A one-shot
+ * grid geometry (orbgpu_matcher_set_grid_geometry) still moves the query origin;
+ * its build origin must be the frame's bounds. */
+int orbgpu_search_by_projection_frame(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q,
+                                      const uint8_t *qdesc, int32_t nq, const orbgpu_frame *train,
+                                      const uint8_t *occupied, int32_t *assign, int32_t th_dist,
+                                      float nnratio, int32_t check_orientation, int32_t *nmatches);
+int orbgpu_search_in_area_frame(orbgpu_matcher *m, const orbgpu_wquery *queries,
+                                const uint8_t *query_desc, int32_t nq, const orbgpu_frame *train,
+                                const float *inv_sigma2, int32_t nlevels, int32_t chi2_gate,
+                                int32_t th_dist, int32_t *qmatch, int32_t *nmatches);
+int orbgpu_search_by_bow_frame(orbgpu_matcher *m, const orbgpu_wquery *queries,
+                               const uint8_t *query_desc, int32_t nq, const orbgpu_frame *train,
+                               const int32_t *seg_start, const int32_t *seg_index, int32_t nseg,
+                               const uint8_t *excluded, int32_t th_dist, float nnratio,
+                               int32_t check_orientation, int32_t *assign, int32_t *qmatch,
+                               int32_t *nmatches);
+/* use_uright = 0 for a monocular keyframe (uright2 == NULL in the array version). */
+int orbgpu_search_for_triangulation_frame(orbgpu_matcher *m, const orbgpu_wquery *queries,
+                                          const uint8_t *query_desc, int32_t nq,
+                                          const orbgpu_frame *train, int32_t use_uright,
+                                          const int32_t *seg_start, const int32_t *seg_index,
+                                          int32_t nseg, const uint8_t *excluded, const float *F12,
+                                          float ex, float ey, const float *scale2,
+                                          const float *sigma2, int32_t nlevels, int32_t only_stereo,
+                                          int32_t check_orientation, int32_t *qmatch,
+                                          int32_t *nmatches);
+/* SearchForInitialization(F1, F2, ...) (src/ORBmatcher.cc:422-571) between two
+ * frames: only vbPrevMatched travels (prev_matched_xy[2*N1] in/out), matches12[N1]
+ * comes back. */
+int orbgpu_search_for_initialization_frames(orbgpu_matcher *m, const orbgpu_frame *f1,
+                                            const orbgpu_frame *f2, float *prev_matched_xy,
+                                            int32_t *matches12, int32_t window_size, float nnratio,
+                                            int32_t check_orientation, int32_t *nmatches);
+
 /* ---- ORBVocabulary (DBoW2) ---------------------------------------------- */
 /* Citations in this block are relative to Thirdparty/DBoW2/DBoW2/ of the reference. */
 

@@ -41,6 +41,10 @@ EXPORTS = [
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
     "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_in_area", "orbgpu_assign_features_to_grid",
     "orbgpu_distinctive_descriptors", "orbgpu_stereo_from_rgbd", "orbgpu_undistort_keypoints", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
+    "orbgpu_frame_create", "orbgpu_frame_destroy", "orbgpu_frame_build_mono", "orbgpu_frame_build_rgbd", "orbgpu_frame_build_stereo", "orbgpu_frame_upload",
+    "orbgpu_frame_size", "orbgpu_frame_download", "orbgpu_frame_grid", "orbgpu_frame_device",
+    "orbgpu_search_by_projection_frame", "orbgpu_search_in_area_frame", "orbgpu_search_by_bow_frame",
+    "orbgpu_search_for_triangulation_frame", "orbgpu_search_for_initialization_frames",
     "orbgpu_vocabulary_create", "orbgpu_vocabulary_load_text", "orbgpu_vocabulary_destroy", "orbgpu_vocabulary_set_stream",
     "orbgpu_vocabulary_sync", "orbgpu_vocabulary_info", "orbgpu_vocabulary_transform", "orbgpu_vocabulary_transform_batch_device",
 ]
@@ -118,6 +122,24 @@ def load_library():
         L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                        C.POINTER(i32)]
         L.orbgpu_stereo_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
+        L.orbgpu_frame_create.argtypes = [i32, i32, C.POINTER(vp)]
+        L.orbgpu_frame_destroy.argtypes = [vp]
+        L.orbgpu_frame_destroy.restype = None
+        L.orbgpu_frame_build_mono.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]
+        L.orbgpu_frame_build_rgbd.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, f32, vp, vp, vp, C.POINTER(i32)]
+        L.orbgpu_frame_build_stereo.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, C.POINTER(i32),
+                                                C.POINTER(i32)]
+        L.orbgpu_frame_upload.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
+        L.orbgpu_frame_size.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.orbgpu_frame_download.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orbgpu_frame_grid.argtypes = [vp, vp, vp, C.POINTER(i32)]
+        L.orbgpu_frame_device.argtypes = [vp] + [C.POINTER(vp)] * 6
+        L.orbgpu_search_by_projection_frame.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32, C.POINTER(i32)]
+        L.orbgpu_search_in_area_frame.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
+        L.orbgpu_search_by_bow_frame.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, f32, i32, vp, vp, C.POINTER(i32)]
+        L.orbgpu_search_for_triangulation_frame.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, f32, f32, vp, vp, i32,
+                                                            i32, i32, vp, C.POINTER(i32)]
+        L.orbgpu_search_for_initialization_frames.argtypes = [vp, vp, vp, vp, vp, i32, f32, i32, C.POINTER(i32)]
         L.orbgpu_vocabulary_create.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]
         L.orbgpu_vocabulary_load_text.argtypes = [i32, C.c_char_p, C.POINTER(vp)]
         L.orbgpu_vocabulary_destroy.argtypes = [vp]
@@ -328,6 +350,114 @@ class _PyramidView:
 
     def __getitem__(self, level):
         return self._ex.pyramid_level(level)
+
+
+class Frame:
+    """The device-resident state of a Frame (orbgpu_frame in include/orbgpu.h): mvKeys, mvKeysUn, mDescriptors,
+    mvuRight, mvDepth and mGrid as the constructors of src/Frame.cc:58-226 leave them, kept on the GPU.  The host
+    mirrors below are fetched on first use."""
+
+    def __init__(self, capacity, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        _check(self._lib.orbgpu_frame_create(device, int(capacity), C.byref(self._h)), "orbgpu_frame_create")
+        self.capacity = int(capacity)
+        self._cache = {}
+        self.N = 0
+        self.nvalid = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.orbgpu_frame_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _cam(K4, dist5, bounds):
+        return (np.ascontiguousarray(K4, np.float32), np.ascontiguousarray(dist5, np.float32),
+                np.ascontiguousarray(bounds, np.float32))
+
+    def _built(self, n):
+        self._cache = {}
+        self.N = n.value
+        nv = C.c_int32()
+        _check(self._lib.orbgpu_frame_size(self._h, None, C.byref(nv), None), "orbgpu_frame_size")
+        self.nvalid = nv.value
+        return self.N
+
+    def build_mono(self, ex, image, K4, dist5, bounds):
+        """Frame::Frame, monocular (src/Frame.cc:175-226).  Returns N."""
+        img = np.ascontiguousarray(image, np.uint8)
+        K, D, b = self._cam(K4, dist5, bounds)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_frame_build_mono(self._h, ex._h, _p(img), img.shape[1], img.shape[0], img.shape[1], _p(K), _p(D),
+                                                 _p(b), C.byref(n)), "orbgpu_frame_build_mono")
+        return self._built(n)
+
+    def build_rgbd(self, ex, image, depth, bf, K4, dist5, bounds):
+        """Frame::Frame, RGB-D (src/Frame.cc:119-172).  Returns N."""
+        img = np.ascontiguousarray(image, np.uint8)
+        dep = np.ascontiguousarray(depth, np.float32)
+        K, D, b = self._cam(K4, dist5, bounds)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_frame_build_rgbd(self._h, ex._h, _p(img), img.shape[1], img.shape[0], img.shape[1], _p(dep),
+                                                 dep.shape[1], bf, _p(K), _p(D), _p(b), C.byref(n)), "orbgpu_frame_build_rgbd")
+        return self._built(n)
+
+    def build_stereo(self, left, right, imL, imR, bf, b_line, K4, dist5, bounds):
+        """Frame::Frame, stereo (src/Frame.cc:58-116).  Returns (N, keypoints with a depth)."""
+        iL = np.ascontiguousarray(imL, np.uint8); iR = np.ascontiguousarray(imR, np.uint8)
+        assert iL.shape == iR.shape
+        K, D, b = self._cam(K4, dist5, bounds)
+        n, nv = C.c_int32(), C.c_int32()
+        _check(self._lib.orbgpu_frame_build_stereo(self._h, left._h, right._h, _p(iL), _p(iR), iL.shape[1], iL.shape[0], iL.shape[1],
+                                                   bf, b_line, _p(K), _p(D), _p(b), C.byref(n), C.byref(nv)),
+               "orbgpu_frame_build_stereo")
+        self._built(n)
+        return self.N, nv.value
+
+    def upload(self, kps_un, desc, bounds, kps=None, uright=None, depth=None, nlevels=8):
+        """A frame from host arrays (orbgpu_frame_upload).  Returns N."""
+        ku = np.ascontiguousarray(kps_un); assert ku.dtype == KEYPOINT_DTYPE
+        d = np.ascontiguousarray(desc, np.uint8)
+        k = None if kps is None else np.ascontiguousarray(kps)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        dp = None if depth is None else np.ascontiguousarray(depth, np.float32)
+        b = np.ascontiguousarray(bounds, np.float32)
+        _check(self._lib.orbgpu_frame_upload(self._h, _p(k), _p(ku), _p(d), _p(ur), _p(dp), len(ku), nlevels, _p(b)),
+               "orbgpu_frame_upload")
+        n = C.c_int32(len(ku))
+        return self._built(n)
+
+    def _fetch(self, which):
+        if which not in self._cache:
+            n = max(self.N, 1)
+            bufs = {"mvKeys": np.zeros(n, KEYPOINT_DTYPE), "mvKeysUn": np.zeros(n, KEYPOINT_DTYPE),
+                    "mDescriptors": np.zeros((n, 32), np.uint8), "mvuRight": np.zeros(n, np.float32),
+                    "mvDepth": np.zeros(n, np.float32)}
+            order = ["mvKeys", "mvKeysUn", "mDescriptors", "mvuRight", "mvDepth"]
+            args = [_p(bufs[k]) if k == which else None for k in order]
+            _check(self._lib.orbgpu_frame_download(self._h, *args), "orbgpu_frame_download")
+            self._cache[which] = bufs[which][:self.N]
+        return self._cache[which]
+
+    mvKeys = property(lambda self: self._fetch("mvKeys"))
+    mvKeysUn = property(lambda self: self._fetch("mvKeysUn"))
+    mDescriptors = property(lambda self: self._fetch("mDescriptors"))
+    mvuRight = property(lambda self: self._fetch("mvuRight"))
+    mvDepth = property(lambda self: self._fetch("mvDepth"))
+
+    def grid(self):
+        """mGrid as (cell_start[64*48+1], cell_index), cell = ix*48 + iy (src/Frame.cc:270-293)."""
+        cs = np.zeros(64 * 48 + 1, np.int32); ci = np.zeros(max(self.N, 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_frame_grid(self._h, _p(cs), _p(ci), C.byref(n)), "orbgpu_frame_grid")
+        return cs, ci[:n.value].copy()
 
 
 def bow_segments(featvec1, featvec2, valid1):
@@ -560,6 +690,86 @@ class ORBmatcher:
                                              _p(kpsR), _p(descR), len(kpsR), bf, b, _p(uR), _p(dep), C.byref(n)),
                "orbgpu_stereo_match")
         return n.value, uR[:len(kpsL)].copy(), dep[:len(kpsL)].copy()
+
+    # ---- the same searches against a device-resident Frame (nothing of the train side is uploaded) ----
+
+    def SearchByProjectionFrame(self, mode, queries, qdesc, frame, occupied=None, th_dist=TH_HIGH):
+        q = np.ascontiguousarray(queries); assert q.dtype == WQUERY_DTYPE
+        qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        assign = np.zeros(max(frame.N, 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_by_projection_frame(self._h, mode, _p(q), _p(qdesc), len(q), frame._h, _p(oc), _p(assign),
+                                                           th_dist, self.mfNNratio, int(self.mbCheckOrientation), C.byref(n)),
+               "orbgpu_search_by_projection_frame")
+        return n.value, assign[:frame.N].copy()
+
+    def SearchInAreaFrame(self, queries, qdesc, frame, inv_sigma2=None, chi2_gate=False, th_dist=TH_LOW):
+        q = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        sg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+        qm = np.zeros(max(len(q), 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_in_area_frame(self._h, _p(q), _p(qdesc), len(q), frame._h, _p(sg), 0 if sg is None else len(sg),
+                                                     int(chi2_gate), th_dist, _p(qm), C.byref(n)), "orbgpu_search_in_area_frame")
+        return n.value, qm[:len(q)].copy()
+
+    def SearchByBoWFrame(self, featvec1, kps1, desc1, valid1, featvec2, frame2, excluded2=None, strict=False):
+        kps1 = np.ascontiguousarray(kps1); desc1 = np.ascontiguousarray(desc1, np.uint8)
+        q_index, q_seg, seg_start, seg_index = bow_segments(featvec1, featvec2, valid1)
+        q = np.zeros(max(len(q_index), 1), WQUERY_DTYPE)[:len(q_index)]
+        q["angle"] = kps1["angle"][q_index]; q["minLevel"] = q_seg; q["flags"] = 1
+        qd = np.ascontiguousarray(desc1[q_index]) if len(q_index) else np.zeros((0, 32), np.uint8)
+        ex = None if excluded2 is None else np.ascontiguousarray(excluded2, np.uint8)
+        n2 = frame2.N
+        assign = np.zeros(max(n2, 1), np.int32); qm = np.zeros(max(len(q), 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_by_bow_frame(self._h, _p(q), _p(qd), len(q), frame2._h, _p(seg_start), _p(seg_index),
+                                                    len(seg_start) - 1, _p(ex), TH_LOW - 1 if strict else TH_LOW, self.mfNNratio,
+                                                    int(self.mbCheckOrientation), _p(assign), _p(qm), C.byref(n)),
+               "orbgpu_search_by_bow_frame")
+        assign = assign[:n2]
+        a1 = np.where(assign >= 0, q_index[np.clip(assign, 0, None)] if len(q_index) else -1, -1).astype(np.int32)
+        m12 = np.full(len(kps1), -1, np.int32)
+        qm = qm[:len(q)]
+        if len(q_index):
+            m12[q_index[qm >= 0]] = qm[qm >= 0]
+        return n.value, a1, m12
+
+    def SearchForTriangulationFrame(self, featvec1, kps1, desc1, has_mp1, uright1, featvec2, frame2, has_mp2, use_uright2, F12,
+                                    epipole, scale2, sigma2, bOnlyStereo=False):
+        kps1 = np.ascontiguousarray(kps1); desc1 = np.ascontiguousarray(desc1, np.uint8)
+        stereo1 = np.zeros(len(kps1), bool) if uright1 is None else np.asarray(uright1) >= 0
+        use1 = ~np.asarray(has_mp1, bool) & (stereo1 if bOnlyStereo else True)
+        q_index, q_seg, seg_start, seg_index = bow_segments(featvec1, featvec2, use1)
+        q = np.zeros(max(len(q_index), 1), WQUERY_DTYPE)[:len(q_index)]
+        q["u"] = kps1["x"][q_index]; q["v"] = kps1["y"][q_index]; q["angle"] = kps1["angle"][q_index]
+        q["minLevel"] = q_seg; q["flags"] = 1 + 4 * stereo1[q_index]
+        qd = np.ascontiguousarray(desc1[q_index]) if len(q_index) else np.zeros((0, 32), np.uint8)
+        ex2 = np.ascontiguousarray(has_mp2, np.uint8)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2, np.float32)
+        qm = np.zeros(max(len(q), 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_for_triangulation_frame(self._h, _p(q), _p(qd), len(q), frame2._h, int(use_uright2),
+                                                               _p(seg_start), _p(seg_index), len(seg_start) - 1, _p(ex2), _p(F),
+                                                               float(epipole[0]), float(epipole[1]), _p(sc), _p(sg), len(sc),
+                                                               int(bOnlyStereo), int(self.mbCheckOrientation), _p(qm), C.byref(n)),
+               "orbgpu_search_for_triangulation_frame")
+        m12 = np.full(len(kps1), -1, np.int32)
+        qm = qm[:len(q)]
+        if len(q_index):
+            m12[q_index[qm >= 0]] = qm[qm >= 0]
+        return n.value, m12
+
+    def SearchForInitializationFrames(self, frame1, frame2, vbPrevMatched, windowSize=10):
+        """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
+        m12 = np.zeros(max(frame1.N, 1), np.int32)
+        n = C.c_int32()
+        _check(self._lib.orbgpu_search_for_initialization_frames(self._h, frame1._h, frame2._h, _p(prev), _p(m12), windowSize,
+                                                                 self.mfNNratio, int(self.mbCheckOrientation), C.byref(n)),
+               "orbgpu_search_for_initialization_frames")
+        return n.value, m12[:frame1.N].copy(), prev
 
     def search_by_projection_batch_device(self, mode, npairs, d_q, d_qdesc, d_nq, q_cap, d_kps2, d_desc2, d_n2, t_cap,
                                           bounds, d_assign, d_nmatches, th_dist=TH_HIGH, d_uright2=0, d_occupied=0):

@@ -886,27 +886,20 @@ static int extract_batch_chunked(orbgpu_extractor *e, const uint8_t *const *imgs
     return ORBGPU_OK;
 }
 
-int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h,
-                         int32_t stride, orbgpu_keypoint *kps, uint8_t *desc, int32_t capacity, int32_t *counts)
+}  // extern "C"
+
+// The host-image path up to, but not including, the wait for the GPU: the images go through the handle's page-locked
+// staging block to the device, the extraction is enqueued (as a HIP graph for a few frames: upload, kernels and the
+// download of the output block replay as one launch) and *X says where the results are: on the device in the handle's
+// output block until the handle's next call, and in its page-locked block once the stream has been waited for.
+int orbgpu::extract_host_enqueue(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h, int32_t stride,
+                                 HostExtraction *X)
 {
-    if (!e || !imgs || !kps || !desc || !counts || nimg < 1 || capacity < 0 || stride < w) {
-        set_error("orbgpu_extract_batch: invalid argument");
-        return ORBGPU_E_INVALID;
-    }
-    if (nimg > e->p.max_batch) {
-        set_error("batch of %d exceeds max_batch %d", nimg, e->p.max_batch);
-        return ORBGPU_E_INVALID;
-    }
-    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
-    int rc = set_geometry(e, w, h);
-    if (rc) return rc;
+    int rc;
     hipStream_t st = e->stream;
     const int cap = e->G.total_kp_cap;
     uint8_t *h_in = (uint8_t *)e->h_pinned + (size_t)e->p.max_batch * cap * (sizeof(orbgpu_keypoint) + 32) + (size_t)e->p.max_batch * 4 + 64;
     // the previous call's device-to-host copies have completed (every host entry point synchronises)
-    for (int f = 0; f < nimg; f++)
-        if (!imgs[f]) { set_error("image %d is NULL", f); return ORBGPU_E_INVALID; }
-    if (nimg >= kChunkMin && !e->profile) return extract_batch_chunked(e, imgs, nimg, w, h, stride, kps, desc, capacity, counts);
     // pageable -> pinned on the host (a 2-D copy from pageable memory stalls for milliseconds); a batch is copied by
     // a few threads, one host thread moves only a few GB/s
     parallel_frames(nimg, [&](int f) {
@@ -915,16 +908,19 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
         else for (int y = 0; y < h; y++) memcpy(hin + (size_t)y * w, imgs[f] + (size_t)y * stride, (size_t)w);
     });
     uint8_t *hp = (uint8_t *)e->h_pinned;
-    orbgpu_keypoint *h_kps = (orbgpu_keypoint *)hp;
-    uint8_t *h_desc = hp + (size_t)nimg * cap * sizeof(orbgpu_keypoint);
-    int32_t *h_counts = (int32_t *)(h_desc + (size_t)nimg * cap * 32);
-    int32_t *h_status = h_counts + nimg;
+    X->h_kps = (const orbgpu_keypoint *)hp;
+    X->h_desc = hp + (size_t)nimg * cap * sizeof(orbgpu_keypoint);
+    X->h_counts = (const int32_t *)(X->h_desc + (size_t)nimg * cap * 32);
+    X->h_status = X->h_counts + nimg;
+    X->cap = cap;
+    X->stream = st;
     // upload, extraction, downloads: every address involved belongs to the handle, so the sequence is the same for
     // every call with this geometry and batch size
     // device block of this call, laid out like the pinned one: keypoints | descriptors | counts | status word
     orbgpu_keypoint *d_k = (orbgpu_keypoint *)e->st_out.p;
     uint8_t *d_d = (uint8_t *)(d_k + (size_t)nimg * cap);
     int32_t *d_c = (int32_t *)(d_d + (size_t)nimg * cap * 32);
+    X->d_kps = d_k; X->d_desc = d_d; X->d_counts = d_c;
     e->status_cur = d_c + nimg;
     const size_t block_bytes = (size_t)nimg * cap * (sizeof(orbgpu_keypoint) + 32) + (size_t)nimg * 4 + 4;
     auto enqueue = [&]() -> int {
@@ -965,13 +961,58 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
     } else {
         if ((rc = enqueue())) return rc;
     }
-    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
-    if (*h_status) {
-        set_error("internal capacity exceeded (status %d)", *h_status);
+    return ORBGPU_OK;
+}
+
+// Argument checks and geometry of the host-image entry points; then extract_host_enqueue.
+int orbgpu::extract_host_begin(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h, int32_t stride,
+                               HostExtraction *X)
+{
+    if (!e || !imgs || nimg < 1 || stride < w || w < 1 || h < 1) {
+        set_error("extract: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (nimg > e->p.max_batch) {
+        set_error("batch of %d exceeds max_batch %d", nimg, e->p.max_batch);
+        return ORBGPU_E_INVALID;
+    }
+    for (int f = 0; f < nimg; f++)
+        if (!imgs[f]) { set_error("image %d is NULL", f); return ORBGPU_E_INVALID; }
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    int rc = set_geometry(e, w, h);
+    if (rc) return rc;
+    return extract_host_enqueue(e, imgs, nimg, w, h, stride, X);
+}
+
+extern "C" {
+
+int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h,
+                         int32_t stride, orbgpu_keypoint *kps, uint8_t *desc, int32_t capacity, int32_t *counts)
+{
+    if (!e || !imgs || !kps || !desc || !counts || nimg < 1 || capacity < 0 || stride < w) {
+        set_error("orbgpu_extract_batch: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (nimg > e->p.max_batch) {
+        set_error("batch of %d exceeds max_batch %d", nimg, e->p.max_batch);
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
+    int rc = set_geometry(e, w, h);
+    if (rc) return rc;
+    for (int f = 0; f < nimg; f++)
+        if (!imgs[f]) { set_error("image %d is NULL", f); return ORBGPU_E_INVALID; }
+    if (nimg >= kChunkMin && !e->profile) return extract_batch_chunked(e, imgs, nimg, w, h, stride, kps, desc, capacity, counts);
+    HostExtraction X;
+    if ((rc = extract_host_enqueue(e, imgs, nimg, w, h, stride, &X))) return rc;
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(X.stream));
+    if (*X.h_status) {
+        set_error("internal capacity exceeded (status %d)", *X.h_status);
         return ORBGPU_E_CAPACITY;
     }
+    const int cap = X.cap;
     for (int f = 0; f < nimg; f++) {
-        const int n = h_counts[f];
+        const int n = X.h_counts[f];
         if (n > capacity) {
             set_error("frame %d has %d keypoints but capacity is %d", f, n, capacity);
             return ORBGPU_E_CAPACITY;
@@ -979,9 +1020,9 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
         counts[f] = n;
     }
     parallel_frames(nimg, [&](int f) {
-        const int n = h_counts[f];
-        memcpy(kps + (size_t)f * capacity, h_kps + (size_t)f * cap, (size_t)n * sizeof(orbgpu_keypoint));
-        memcpy(desc + (size_t)f * capacity * 32, h_desc + (size_t)f * cap * 32, (size_t)n * 32);
+        const int n = X.h_counts[f];
+        memcpy(kps + (size_t)f * capacity, X.h_kps + (size_t)f * cap, (size_t)n * sizeof(orbgpu_keypoint));
+        memcpy(desc + (size_t)f * capacity * 32, X.h_desc + (size_t)f * cap * 32, (size_t)n * 32);
     });
     return ORBGPU_OK;
 }

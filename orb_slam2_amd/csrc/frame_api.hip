@@ -1,0 +1,562 @@
+// The device-resident frame: what the constructors of Frame compute directly after the extraction
+// (src/Frame.cc:58-116 stereo, :119-172 RGB-D, :175-226 monocular) -- UndistortKeyPoints, ComputeStereoMatches or
+// ComputeStereoFromRGBD, AssignFeaturesToGrid -- enqueued behind the extraction on the extractor's stream, with the
+// results kept in the frame's own device buffers.  The host waits once, for the keypoint count.
+// Reference lines are relative to /root/reference/src/ORB_SLAM2/.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "frame_internal.h"
+#include "orbgpu_internal.h"
+
+namespace orbgpu {
+int launch_grid_only(hipStream_t st, const MatchArgs &A);
+int launch_stereo(hipStream_t st, const StereoArgs &A);
+
+struct FrameOut {
+    orbgpu_keypoint *kps, *kps_un;
+    uint8_t *desc;
+    float *uright, *depth;
+    int32_t *count;
+    int capacity;
+};
+
+// mode 0: monocular (mvuRight = mvDepth = -1, src/Frame.cc:203-204); 1: RGB-D (ComputeStereoFromRGBD, :777-798: depth
+// image lookup at the distorted keypoint, truncated to integer pixel coordinates as cv::Mat::at<float>(float, float)
+// does); 2: stereo (k_stereo fills uRight / depth afterwards).  The count arrives in device memory.
+__global__ __launch_bounds__(256) void k_frame_finish(const orbgpu_keypoint *__restrict__ src_kps, const uint8_t *__restrict__ src_desc,
+                                                      const int32_t *__restrict__ src_count, FrameOut F, UndistortArgs U, int distorted,
+                                                      const float *__restrict__ depth_img, int w, int h, int stride_floats, float bf,
+                                                      int mode)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(max(*src_count, 0), F.capacity);
+    if (i == 0) {
+        F.count[0] = n;
+        if (mode != 1) F.count[1] = 0;  // RGB-D counts its depths with atomics: the host clears that word before the launch
+    }
+    if (i >= n) return;
+    const orbgpu_keypoint kp = src_kps[i];
+    orbgpu_keypoint un = kp;
+    if (distorted) undistort_point(U, kp.x, kp.y, &un.x, &un.y);  // :519-523: a plain copy when k1 == 0
+    F.kps[i] = kp;
+    F.kps_un[i] = un;
+    const uint4 *sd = reinterpret_cast<const uint4 *>(src_desc) + 2 * (size_t)i;
+    uint4 *dd = reinterpret_cast<uint4 *>(F.desc) + 2 * (size_t)i;
+    dd[0] = sd[0];
+    dd[1] = sd[1];
+    if (mode == 0) {
+        F.uright[i] = -1.0f;
+        F.depth[i] = -1.0f;
+    } else if (mode == 1) {
+        const int v = (int)kp.y, u = (int)kp.x;
+        float d = 0.0f;
+        if (u >= 0 && u < w && v >= 0 && v < h) d = depth_img[(size_t)v * stride_floats + u];
+        if (d > 0) {
+            F.depth[i] = d;
+            F.uright[i] = __fsub_rn(un.x, __fdiv_rn(bf, d));
+            atomicAdd(&F.count[1], 1);
+        } else {
+            F.depth[i] = -1.0f;
+            F.uright[i] = -1.0f;
+        }
+    }
+}
+
+// Row table of ComputeStereoMatches (src/Frame.cc:610-627): right keypoint iR is listed in rows floor(y - r) ..
+// ceil(y + r), r = 2 * scale[octave]; every row lists its keypoints in ascending iR.  One workgroup: counts by LDS
+// atomics, a scan, then a thread per row walks the keypoints in order (their row spans staged in LDS by chunks).
+constexpr int kRowChunk = 4096;
+__global__ __launch_bounds__(1024) void k_stereo_rows(const orbgpu_keypoint *__restrict__ kpsR, const int32_t *__restrict__ d_nR, int capR,
+                                                      ScaleTab scale, int nlevels, int nRows, int32_t *__restrict__ row_start,
+                                                      int32_t *__restrict__ row_items)
+{
+    extern __shared__ int rows_lds[];  // nRows + 1 counts, then write cursors
+    __shared__ int scan_lds[33];
+    __shared__ short2 span[kRowChunk];
+    const int tid = threadIdx.x;
+    const int nR = min(max(*d_nR, 0), capR);
+    auto row_span = [&](int iR) {
+        const orbgpu_keypoint kp = kpsR[iR];
+        const float r = __fmul_rn(2.0f, scale.s[min(max(kp.octave, 0), nlevels - 1)]);
+        const int maxr = (int)ceilf(__fadd_rn(kp.y, r)), minr = (int)floorf(__fsub_rn(kp.y, r));
+        return make_int2(max(minr, 0), min(maxr, nRows - 1));
+    };
+    for (int y = tid; y <= nRows; y += 1024) rows_lds[y] = 0;
+    __syncthreads();
+    for (int iR = tid; iR < nR; iR += 1024) {
+        const int2 s = row_span(iR);
+        for (int y = s.x; y <= s.y; y++) atomicAdd(&rows_lds[y], 1);
+    }
+    __syncthreads();
+    int carry = 0;
+    for (int b = 0; b < nRows; b += 1024) {
+        const int y = b + tid;
+        const int v = y < nRows ? rows_lds[y] : 0;
+        int total;
+        const int ex = block_scan_excl(v, &total, scan_lds);
+        if (y < nRows) {
+            rows_lds[y] = carry + ex;
+            row_start[y] = carry + ex;
+        }
+        carry += total;
+    }
+    if (tid == 0) row_start[nRows] = carry;
+    __syncthreads();
+    for (int c0 = 0; c0 < nR; c0 += kRowChunk) {
+        const int cn = min(kRowChunk, nR - c0);
+        for (int j = tid; j < cn; j += 1024) {
+            const int2 s = row_span(c0 + j);
+            span[j] = make_short2((short)s.x, (short)s.y);  // an empty span (below row 0 or past the last row) has x > y
+        }
+        __syncthreads();
+        for (int y = tid; y < nRows; y += 1024) {
+            int cur = rows_lds[y];
+            for (int j = 0; j < cn; j++) {
+                const short2 s = span[j];  // the same address for every lane: a broadcast
+                if (s.x <= y && y <= s.y) row_items[cur++] = c0 + j;
+            }
+            rows_lds[y] = cur;
+        }
+        __syncthreads();
+    }
+}
+
+// Outlier rejection of ComputeStereoMatches (src/Frame.cc:760-773): the median of the matched SADs is element
+// size / 2 of their ascending order; matches with SAD >= 1.5 * 1.4 * median lose their measurement.  The SAD of an
+// 11 x 11 window of bytes is below 2^15: the median comes out of a histogram of the high eight bits and one of the
+// low seven bits inside the bucket that holds it.
+__global__ __launch_bounds__(1024) void k_stereo_outliers(const int32_t *__restrict__ best_sad, const int32_t *__restrict__ d_nL, int capL,
+                                                          float *__restrict__ uRight, float *__restrict__ depth, int32_t *__restrict__ nvalid_out)
+{
+    __shared__ int hist[256];
+    __shared__ int removed;
+    const int tid = threadIdx.x;
+    const int n = min(max(*d_nL, 0), capL);
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) removed = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int s = best_sad[i];
+        if (s >= 0) atomicAdd(&hist[min(s >> 7, 255)], 1);
+    }
+    __syncthreads();
+    // every thread walks the histogram itself (broadcast reads): the number of matches, the bucket of the median and
+    // the matches below that bucket
+    int total = 0;
+    for (int k = 0; k < 256; k++) total += hist[k];
+    if (total == 0) {
+        if (tid == 0) *nvalid_out = 0;
+        return;
+    }
+    const int kmed = total / 2;
+    int b = 0, acc = 0;
+    for (; b < 255; b++) {
+        if (kmed < acc + hist[b]) break;
+        acc += hist[b];
+    }
+    __syncthreads();
+    if (tid < 128) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int s = best_sad[i];
+        if (s >= 0 && min(s >> 7, 255) == b) atomicAdd(&hist[s & 127], 1);
+    }
+    __syncthreads();
+    int lo = 0;
+    for (; lo < 127; lo++) {
+        if (kmed < acc + hist[lo]) break;
+        acc += hist[lo];
+    }
+    const int bucket = (b << 7) | lo;
+    const float median = (float)bucket;
+    const float thDist = __fmul_rn(1.5f * 1.4f, median);
+    int mine = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const int s = best_sad[i];
+        if (s >= 0 && !((float)s < thDist)) {
+            uRight[i] = -1.0f;
+            depth[i] = -1.0f;
+            mine++;
+        }
+    }
+    if (mine) atomicAdd(&removed, mine);
+    __syncthreads();
+    if (tid == 0) *nvalid_out = total - removed;
+}
+
+}  // namespace orbgpu
+
+using namespace orbgpu;
+
+static int frame_check(const char *who, orbgpu_frame *f, const float *K4, const float *dist5, const float *bounds4, int32_t *n_out)
+{
+    if (!f || !K4 || !dist5 || !bounds4 || !n_out || K4[0] == 0.0f || K4[1] == 0.0f || !(bounds4[2] > bounds4[0]) ||
+        !(bounds4[3] > bounds4[1])) {
+        set_error("%s: invalid argument", who);
+        return ORBGPU_E_INVALID;
+    }
+    return ORBGPU_OK;
+}
+
+static int frame_stereo_block(orbgpu_frame *f, size_t bytes)
+{
+    if (bytes <= f->stereo_bytes) return ORBGPU_OK;
+    if (f->stereo_block) (void)hipFree(f->stereo_block);
+    f->stereo_block = nullptr;
+    f->stereo_bytes = 0;
+    if (hipMalloc(&f->stereo_block, bytes) != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed", bytes);
+        return ORBGPU_E_NOMEM;
+    }
+    f->stereo_bytes = bytes;
+    return ORBGPU_OK;
+}
+
+// Frame::AssignFeaturesToGrid (src/Frame.cc:270-293) into the frame's grid block, in the window matcher's layout.
+static int frame_grid_enqueue(orbgpu_frame *f, hipStream_t st)
+{
+    MatchArgs A;
+    memset(&A, 0, sizeof(A));
+    A.mode = 1;
+    A.nq = f->count + 3;  // always 0
+    A.q_cap = 1;
+    A.kps2 = f->kps_un; A.desc2 = f->desc; A.n2 = f->count; A.t_cap = f->capacity;
+    A.gminX = A.qminX = f->bounds4[0]; A.gminY = A.qminY = f->bounds4[1];  // src/Frame.cc:101-102
+    A.invW = (float)ORBGPU_GRID_COLS / (f->bounds4[2] - f->bounds4[0]);
+    A.invH = (float)ORBGPU_GRID_ROWS / (f->bounds4[3] - f->bounds4[1]);
+    A.scratch = f->gscratch;
+    return launch_grid_only(st, A);
+}
+
+static int frame_finish_enqueue(orbgpu_frame *f, const HostExtraction &X, const float *K4, const float *dist5, int mode,
+                                const float *d_depth, int w, int h, float bf)
+{
+    FrameOut F = {f->kps, f->kps_un, f->desc, f->uright, f->depth, f->count, f->capacity};
+    f->distorted = dist5[0] != 0.0f;
+    if (mode == 1) ORBGPU_HIP_CHECK(hipMemsetAsync(f->count, 0, 16, X.stream));
+    hipLaunchKernelGGL(k_frame_finish, dim3((f->capacity + 255) / 256), dim3(256), 0, X.stream, X.d_kps, X.d_desc, X.d_counts, F,
+                       undistort_args(K4, dist5), dist5[0] != 0.0f ? 1 : 0, d_depth, w, h, w, bf, mode);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+// Wait for the build, check the extraction's flags and note the counts on the host.  The keypoint count, the
+// keypoints and the descriptors are in the extractor's page-locked block by then; only a stereo / RGB-D build
+// has a second number to fetch.
+static int frame_complete(orbgpu_frame *f, const HostExtraction &X, const HostExtraction *XR, bool want_nvalid, int32_t *n_out)
+{
+    int32_t hc[4] = {0, 0, 0, 0};
+    if (want_nvalid) ORBGPU_HIP_CHECK(hipMemcpyAsync(hc, f->count, 16, hipMemcpyDeviceToHost, X.stream));
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(X.stream));
+    if (*X.h_status || (XR && *XR->h_status)) {
+        set_error("internal capacity exceeded (status %d)", *X.h_status ? *X.h_status : *XR->h_status);
+        return ORBGPU_E_CAPACITY;
+    }
+    const int n = X.h_counts[0];
+    if (n > f->capacity) {
+        set_error("the frame holds %d keypoints, the image yields %d", f->capacity, n);
+        return ORBGPU_E_CAPACITY;
+    }
+    f->h_kps.assign(X.h_kps, X.h_kps + n);
+    f->h_desc.assign(X.h_desc, X.h_desc + (size_t)n * 32);
+    f->h_valid = true;
+    f->n = n;
+    f->nvalid = hc[1];
+    f->built = true;
+    *n_out = f->n;
+    return ORBGPU_OK;
+}
+
+static int frame_begin(orbgpu_frame *f, orbgpu_extractor *e, const float *bounds4)
+{
+    ORBGPU_HIP_CHECK(hipSetDevice(f->device));
+    int32_t nlev = 0;
+    int rc = orbgpu_extractor_tables(e, &nlev, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    f->nlevels = nlev;
+    f->built = false;
+    f->h_valid = false;
+    memcpy(f->bounds4, bounds4, sizeof(f->bounds4));
+    return ORBGPU_OK;
+}
+
+extern "C" {
+
+int orbgpu_frame_create(int32_t device, int32_t capacity, orbgpu_frame **out)
+{
+    if (!out || capacity < 1 || capacity > (1 << 20)) {
+        set_error("orbgpu_frame_create: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    *out = nullptr;
+    ORBGPU_HIP_CHECK(hipSetDevice(device));
+    orbgpu_frame *f = new (std::nothrow) orbgpu_frame;
+    if (!f) return ORBGPU_E_NOMEM;
+    f->device = device;
+    f->capacity = capacity;
+    const size_t cap = (size_t)capacity;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_kps = 0, o_un = o_kps + up(cap * sizeof(orbgpu_keypoint)), o_desc = o_un + up(cap * sizeof(orbgpu_keypoint)),
+                 o_ur = o_desc + up(cap * 32), o_dep = o_ur + up(cap * 4), o_cnt = o_dep + up(cap * 4), o_grid = o_cnt + 256,
+                 total = o_grid + up(match_scratch_ints(1, capacity) * 4);
+    if (hipMalloc(&f->block, total) != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed", total);
+        delete f;
+        return ORBGPU_E_NOMEM;
+    }
+    uint8_t *b = (uint8_t *)f->block;
+    f->kps = (orbgpu_keypoint *)(b + o_kps);
+    f->kps_un = (orbgpu_keypoint *)(b + o_un);
+    f->desc = b + o_desc;
+    f->uright = (float *)(b + o_ur);
+    f->depth = (float *)(b + o_dep);
+    f->count = (int32_t *)(b + o_cnt);
+    f->gscratch = (int32_t *)(b + o_grid);
+    if (hipMemset(f->count, 0, 256) != hipSuccess || hipEventCreateWithFlags(&f->ev, hipEventDisableTiming) != hipSuccess) {
+        set_error("orbgpu_frame_create: device setup failed");
+        (void)hipFree(f->block);
+        delete f;
+        return ORBGPU_E_HIP;
+    }
+    *out = f;
+    return ORBGPU_OK;
+}
+
+void orbgpu_frame_destroy(orbgpu_frame *f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize();  // matcher calls that read the frame may still be in flight
+    if (f->ev) (void)hipEventDestroy(f->ev);
+    if (f->stereo_block) (void)hipFree(f->stereo_block);
+    if (f->block) (void)hipFree(f->block);
+    delete f;
+}
+
+int orbgpu_frame_build_mono(orbgpu_frame *f, orbgpu_extractor *e, const uint8_t *img, int32_t w, int32_t h, int32_t stride,
+                            const float *K4, const float *dist5, const float *bounds4, int32_t *n_out)
+{
+    int rc = frame_check("orbgpu_frame_build_mono", f, K4, dist5, bounds4, n_out);
+    if (rc) return rc;
+    if ((rc = frame_begin(f, e, bounds4))) return rc;
+    HostExtraction X;
+    const uint8_t *one[1] = {img};
+    if ((rc = extract_host_begin(e, one, 1, w, h, stride, &X))) return rc;
+    if ((rc = frame_finish_enqueue(f, X, K4, dist5, 0, nullptr, w, h, 0.0f))) return rc;
+    if ((rc = frame_grid_enqueue(f, X.stream))) return rc;
+    return frame_complete(f, X, nullptr, false, n_out);
+}
+
+int orbgpu_frame_build_rgbd(orbgpu_frame *f, orbgpu_extractor *e, const uint8_t *img, int32_t w, int32_t h, int32_t stride,
+                            const float *depth, int32_t depth_stride_floats, float bf, const float *K4, const float *dist5,
+                            const float *bounds4, int32_t *n_out)
+{
+    int rc = frame_check("orbgpu_frame_build_rgbd", f, K4, dist5, bounds4, n_out);
+    if (rc) return rc;
+    if (!depth || depth_stride_floats < w) {
+        set_error("orbgpu_frame_build_rgbd: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if ((rc = frame_begin(f, e, bounds4))) return rc;
+    if ((rc = frame_stereo_block(f, (size_t)w * h * 4))) return rc;
+    HostExtraction X;
+    const uint8_t *one[1] = {img};
+    if ((rc = extract_host_begin(e, one, 1, w, h, stride, &X))) return rc;
+    ORBGPU_HIP_CHECK(hipMemcpy2DAsync(f->stereo_block, (size_t)w * 4, depth, (size_t)depth_stride_floats * 4, (size_t)w * 4, (size_t)h,
+                                      hipMemcpyHostToDevice, X.stream));
+    if ((rc = frame_finish_enqueue(f, X, K4, dist5, 1, (const float *)f->stereo_block, w, h, bf))) return rc;
+    if ((rc = frame_grid_enqueue(f, X.stream))) return rc;
+    return frame_complete(f, X, nullptr, true, n_out);
+}
+
+int orbgpu_frame_build_stereo(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_extractor *right, const uint8_t *imgL,
+                              const uint8_t *imgR, int32_t w, int32_t h, int32_t stride, float bf, float b, const float *K4,
+                              const float *dist5, const float *bounds4, int32_t *n_out, int32_t *nvalid_out)
+{
+    int rc = frame_check("orbgpu_frame_build_stereo", f, K4, dist5, bounds4, n_out);
+    if (rc) return rc;
+    if (!left || !right || left == right || !(b > 0)) {
+        set_error("orbgpu_frame_build_stereo: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if ((rc = frame_begin(f, left, bounds4))) return rc;
+    StereoArgs S;
+    memset(&S, 0, sizeof(S));
+    int32_t nlevR = 0;
+    float scaleR[ORBGPU_MAX_LEVELS];
+    if ((rc = orbgpu_extractor_tables(left, &S.nlevels, S.scale, S.inv_scale, nullptr, nullptr, nullptr))) return rc;
+    if ((rc = orbgpu_extractor_tables(right, &nlevR, scaleR, nullptr, nullptr, nullptr, nullptr))) return rc;
+    if (nlevR != S.nlevels || memcmp(scaleR, S.scale, sizeof(float) * (size_t)nlevR) != 0) {
+        set_error("orbgpu_frame_build_stereo: the two extractors have different pyramids");
+        return ORBGPU_E_INVALID;
+    }
+    if (h > 8192) {
+        set_error("orbgpu_frame_build_stereo: images of more than 8192 rows are not supported");
+        return ORBGPU_E_UNSUPPORTED;
+    }
+    // the two extractions run side by side on the two handles' streams (two threads in the reference, :78-81)
+    HostExtraction XL, XR;
+    const uint8_t *oneL[1] = {imgL}, *oneR[1] = {imgR};
+    if ((rc = extract_host_begin(left, oneL, 1, w, h, stride, &XL))) return rc;
+    if ((rc = extract_host_begin(right, oneR, 1, w, h, stride, &XR))) return rc;
+    hipStream_t st = XL.stream;
+    if (XR.stream != st) {
+        ORBGPU_HIP_CHECK(hipEventRecord(f->ev, XR.stream));
+        ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, f->ev, 0));
+    }
+    for (int l = 0; l < S.nlevels; l++) {
+        int32_t w2, h2, p2;
+        if ((rc = orbgpu_pyramid_level_device(left, 0, l, 0, &S.pyrL[l], &S.pitchL[l], &S.w[l], &S.h[l]))) return rc;
+        if ((rc = orbgpu_pyramid_level_device(right, 0, l, 0, &S.pyrR[l], &p2, &w2, &h2))) return rc;
+        S.pitchR[l] = p2;
+    }
+    // stereo working set: best SAD [capacity] | row_start [rows + 1] | row_items; a right keypoint spans at most
+    // 2 r + 3 rows, r = 2 * its level's scale
+    const int nRows = h;
+    const size_t span = (size_t)ceilf(4.0f * S.scale[S.nlevels - 1]) + 3;
+    const size_t items = (size_t)XR.cap * (span < (size_t)nRows ? span : (size_t)nRows);
+    if ((rc = frame_stereo_block(f, ((size_t)f->capacity + (size_t)nRows + 1 + items) * 4))) return rc;
+    int32_t *best_sad = (int32_t *)f->stereo_block, *row_start = best_sad + f->capacity, *row_items = row_start + nRows + 1;
+    if ((rc = frame_finish_enqueue(f, XL, K4, dist5, 2, nullptr, w, h, bf))) return rc;
+    ScaleTab sc;
+    for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) sc.s[l] = S.scale[l < S.nlevels ? l : S.nlevels - 1];
+    hipLaunchKernelGGL(k_stereo_rows, dim3(1), dim3(1024), ((size_t)nRows + 1) * 4, st, XR.d_kps, XR.d_counts, XR.cap, sc, S.nlevels, nRows,
+                       row_start, row_items);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    S.kpsL = f->kps; S.descL = f->desc; S.nL = f->capacity; S.d_nL = f->count;
+    S.kpsR = XR.d_kps; S.descR = XR.d_desc; S.nR = XR.cap;
+    S.row_start = row_start; S.row_items = row_items; S.nRows = nRows;
+    S.bf = bf; S.b = b;
+    S.uRight = f->uright; S.depth = f->depth; S.best_sad = best_sad;
+    if ((rc = launch_stereo(st, S))) return rc;
+    hipLaunchKernelGGL(k_stereo_outliers, dim3(1), dim3(1024), 0, st, best_sad, f->count, f->capacity, f->uright, f->depth, f->count + 1);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    if ((rc = frame_grid_enqueue(f, st))) return rc;
+    if ((rc = frame_complete(f, XL, &XR, true, n_out))) return rc;
+    if (nvalid_out) *nvalid_out = f->nvalid;
+    return ORBGPU_OK;
+}
+
+// A frame from host arrays (a Frame the program computed itself, a KeyFrame read back from a saved map): the
+// arrays are uploaded and the grid is built as AssignFeaturesToGrid does.
+int orbgpu_frame_upload(orbgpu_frame *f, const orbgpu_keypoint *kps, const orbgpu_keypoint *kps_un, const uint8_t *desc,
+                        const float *uright, const float *depth, int32_t n, int32_t nlevels, const float *bounds4)
+{
+    if (!f || n < 0 || (n > 0 && (!kps_un || !desc)) || !bounds4 || !(bounds4[2] > bounds4[0]) || !(bounds4[3] > bounds4[1]) ||
+        nlevels < 1 || nlevels > ORBGPU_MAX_LEVELS) {
+        set_error("orbgpu_frame_upload: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (n > f->capacity) {
+        set_error("orbgpu_frame_upload: the frame holds %d keypoints, %d given", f->capacity, n);
+        return ORBGPU_E_CAPACITY;
+    }
+    for (int i = 0; i < n; i++)
+        if (kps_un[i].octave < 0 || kps_un[i].octave >= nlevels) {
+            set_error("orbgpu_frame_upload: keypoint %d has octave %d of %d levels", i, kps_un[i].octave, nlevels);
+            return ORBGPU_E_INVALID;
+        }
+    ORBGPU_HIP_CHECK(hipSetDevice(f->device));
+    f->built = false;
+    f->nlevels = nlevels;
+    memcpy(f->bounds4, bounds4, sizeof(f->bounds4));
+    int32_t hc[4] = {n, 0, 0, 0};
+    if (n > 0) {
+        ORBGPU_HIP_CHECK(hipMemcpy(f->kps_un, kps_un, (size_t)n * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice));
+        ORBGPU_HIP_CHECK(hipMemcpy(f->kps, kps ? kps : kps_un, (size_t)n * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice));
+        ORBGPU_HIP_CHECK(hipMemcpy(f->desc, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+        std::vector<float> minus((uright && depth) ? 0 : (size_t)n, -1.0f);
+        ORBGPU_HIP_CHECK(hipMemcpy(f->uright, uright ? uright : minus.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        ORBGPU_HIP_CHECK(hipMemcpy(f->depth, depth ? depth : minus.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        if (depth)
+            for (int i = 0; i < n; i++) hc[1] += depth[i] > 0 ? 1 : 0;
+    }
+    ORBGPU_HIP_CHECK(hipMemcpy(f->count, hc, 16, hipMemcpyHostToDevice));
+    int rc = frame_grid_enqueue(f, nullptr);
+    if (rc) return rc;
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(nullptr));
+    const orbgpu_keypoint *hk = kps ? kps : kps_un;
+    f->h_kps.assign(hk, hk + n);
+    f->h_desc.assign(desc, desc + (size_t)n * 32);
+    f->h_valid = true;
+    f->distorted = kps != nullptr && kps != kps_un;  // the two arrays may differ
+    f->n = n;
+    f->nvalid = hc[1];
+    f->built = true;
+    return ORBGPU_OK;
+}
+
+int orbgpu_frame_size(const orbgpu_frame *f, int32_t *n, int32_t *nvalid, int32_t *capacity)
+{
+    if (!f) return ORBGPU_E_INVALID;
+    if (n) *n = f->built ? f->n : 0;
+    if (nvalid) *nvalid = f->built ? f->nvalid : 0;
+    if (capacity) *capacity = f->capacity;
+    return ORBGPU_OK;
+}
+
+int orbgpu_frame_download(orbgpu_frame *f, orbgpu_keypoint *kps, orbgpu_keypoint *kps_un, uint8_t *desc, float *uright, float *depth)
+{
+    if (!f || !f->built) {
+        set_error("orbgpu_frame_download: the frame has not been built");
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(f->device));
+    const size_t n = (size_t)f->n;
+    if (n == 0) return ORBGPU_OK;
+    // keypoints and descriptors came to the host with the extraction: no GPU round trip for them
+    if (kps) {
+        if (f->h_valid) memcpy(kps, f->h_kps.data(), n * sizeof(orbgpu_keypoint));
+        else ORBGPU_HIP_CHECK(hipMemcpy(kps, f->kps, n * sizeof(orbgpu_keypoint), hipMemcpyDeviceToHost));
+    }
+    if (kps_un) {
+        if (f->h_valid && !f->distorted) memcpy(kps_un, f->h_kps.data(), n * sizeof(orbgpu_keypoint));
+        else ORBGPU_HIP_CHECK(hipMemcpy(kps_un, f->kps_un, n * sizeof(orbgpu_keypoint), hipMemcpyDeviceToHost));
+    }
+    if (desc) {
+        if (f->h_valid) memcpy(desc, f->h_desc.data(), n * 32);
+        else ORBGPU_HIP_CHECK(hipMemcpy(desc, f->desc, n * 32, hipMemcpyDeviceToHost));
+    }
+    if (uright) ORBGPU_HIP_CHECK(hipMemcpy(uright, f->uright, n * 4, hipMemcpyDeviceToHost));
+    if (depth) ORBGPU_HIP_CHECK(hipMemcpy(depth, f->depth, n * 4, hipMemcpyDeviceToHost));
+    return ORBGPU_OK;
+}
+
+int orbgpu_frame_grid(orbgpu_frame *f, int32_t *cell_start, int32_t *cell_index, int32_t *n_in_grid)
+{
+    if (!f || !cell_start) {
+        set_error("orbgpu_frame_grid: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    if (!f->built) {
+        set_error("orbgpu_frame_grid: the frame has not been built");
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(f->device));
+    const int ncell = ORBGPU_GRID_COLS * ORBGPU_GRID_ROWS;
+    const int32_t *g = f->grid();
+    ORBGPU_HIP_CHECK(hipMemcpy(cell_start, g, (size_t)(ncell + 1) * 4, hipMemcpyDeviceToHost));
+    const int ng = cell_start[ncell];
+    if (ng > 0 && cell_index)  // the keypoint index is the fourth word of every 16-byte grid record
+        ORBGPU_HIP_CHECK(hipMemcpy2D(cell_index, 4, g + 3080 + 3, 16, 4, (size_t)ng, hipMemcpyDeviceToHost));
+    if (n_in_grid) *n_in_grid = ng;
+    return ORBGPU_OK;
+}
+
+int orbgpu_frame_device(const orbgpu_frame *f, const orbgpu_keypoint **d_kps, const orbgpu_keypoint **d_kps_un, const uint8_t **d_desc,
+                        const float **d_uright, const float **d_depth, const int32_t **d_count)
+{
+    if (!f) return ORBGPU_E_INVALID;
+    if (d_kps) *d_kps = f->kps;
+    if (d_kps_un) *d_kps_un = f->kps_un;
+    if (d_desc) *d_desc = f->desc;
+    if (d_uright) *d_uright = f->uright;
+    if (d_depth) *d_depth = f->depth;
+    if (d_count) *d_count = f->count;
+    return ORBGPU_OK;
+}
+
+}  // extern "C"

@@ -35,6 +35,9 @@ struct MatchArgs {
     // (src/Frame.cc:397-500); a KeyFrame keeps its Frame's grid and inverse cell sizes but queries with its own
     // integer-truncated bounds (include/KeyFrame.h:185, src/KeyFrame.cc:585-624).
     float gminX, gminY, qminX, qminY, invW, invH;
+    // a grid built earlier with the same t_cap and build origin (one pair): cell_start [3080] | grid records
+    // [4*t_cap] | grid descriptors [8*t_cap]; null: the call builds the grid in its scratch
+    const int32_t *grid;
     const uint8_t *occupied;
     int32_t *assign;   // [pair][t_cap]
     int32_t *qmatch;   // [pair][q_cap] or null
@@ -77,6 +80,37 @@ struct StereoArgs {
     int32_t nlevels;
     float bf, b;
     float *uRight; float *depth; int32_t *best_sad;
+    const int32_t *d_nL;  // non-null: the number of left keypoints is read on the device (nL is then the launch bound)
 };
+
+// Frame::UndistortKeyPoints (src/Frame.cc:517-558): cv::undistortPoints(pts, K, D, R = I, P = K),
+// i.e. five fixed-point iterations of the radial + tangential model in double precision
+// (OpenCV 2.4 / 3.x cvUndistortPoints), then re-projection with K; results rounded to float.
+struct UndistortArgs { double fx, fy, cx, cy, k1, k2, p1, p2, k3; };
+inline UndistortArgs undistort_args(const float *K4, const float *D5)
+{
+    UndistortArgs U = {(double)K4[0], (double)K4[1], (double)K4[2], (double)K4[3], (double)D5[0], (double)D5[1],
+                       (double)D5[2], (double)D5[3], (double)D5[4]};
+    return U;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ void undistort_point(const UndistortArgs &U, float px, float py, float *ox, float *oy)
+{
+    const double ifx = 1.0 / U.fx, ify = 1.0 / U.fy;
+    double x = ((double)px - U.cx) * ifx, y = ((double)py - U.cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((U.k3 * r2 + U.k2) * r2 + U.k1) * r2);
+        const double deltaX = 2 * U.p1 * x * y + U.p2 * (r2 + 2 * x * x);
+        const double deltaY = U.p1 * (r2 + 2 * y * y) + 2 * U.p2 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = U.fx * x + 0.0 * y + U.cx, yy = 0.0 * x + U.fy * y + U.cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    *ox = (float)(xx * ww);
+    *oy = (float)(yy * ww);
+}
+#endif
 
 }  // namespace orbgpu

@@ -115,7 +115,7 @@ int launch_bruteforce(hipStream_t st, const uint8_t *d_Q, int nq, const uint8_t 
 __global__ __launch_bounds__(256) void k_stereo(StereoArgs A)
 {
     const int lane = lane_id(), iL = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (iL >= A.nL) return;
+    if (iL >= (A.d_nL ? min(*A.d_nL, A.nL) : A.nL)) return;
     float out_u = -1.0f, out_d = -1.0f;
     int out_sad = -1;
     const orbgpu_keypoint kpL = A.kpsL[iL];
@@ -301,40 +301,21 @@ int launch_stereo_from_rgbd(hipStream_t st, const orbgpu_keypoint *kps, const or
 }
 
 // ---------------------------------------------------------------------------
-// Frame::UndistortKeyPoints (src/Frame.cc:517-558): cv::undistortPoints(pts, K, D, R = I, P = K),
-// i.e. five fixed-point iterations of the radial + tangential model in double precision
-// (OpenCV 2.4 / 3.x cvUndistortPoints), then re-projection with K; results rounded to float.
+// Frame::UndistortKeyPoints (src/Frame.cc:517-558); the arithmetic is undistort_point (match_internal.h).
 // ---------------------------------------------------------------------------
-struct UndistortArgs { double fx, fy, cx, cy, k1, k2, p1, p2, k3; };
-
 __global__ __launch_bounds__(256) void k_undistort(const orbgpu_keypoint *__restrict__ kps, int n, UndistortArgs U,
                                                    orbgpu_keypoint *__restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     orbgpu_keypoint kp = kps[i];
-    const double ifx = 1.0 / U.fx, ify = 1.0 / U.fy;
-    double x = ((double)kp.x - U.cx) * ifx, y = ((double)kp.y - U.cy) * ify;
-    const double x0 = x, y0 = y;
-    for (int j = 0; j < 5; j++) {
-        const double r2 = x * x + y * y;
-        const double icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((U.k3 * r2 + U.k2) * r2 + U.k1) * r2);
-        const double deltaX = 2 * U.p1 * x * y + U.p2 * (r2 + 2 * x * x);
-        const double deltaY = U.p1 * (r2 + 2 * y * y) + 2 * U.p2 * x * y;
-        x = (x0 - deltaX) * icdist;
-        y = (y0 - deltaY) * icdist;
-    }
-    const double xx = U.fx * x + 0.0 * y + U.cx, yy = 0.0 * x + U.fy * y + U.cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
-    kp.x = (float)(xx * ww);
-    kp.y = (float)(yy * ww);
+    undistort_point(U, kp.x, kp.y, &kp.x, &kp.y);
     out[i] = kp;
 }
 
 int launch_undistort(hipStream_t st, const orbgpu_keypoint *kps, int n, const float *K4, const float *D5, orbgpu_keypoint *out)
 {
-    UndistortArgs U = {(double)K4[0], (double)K4[1], (double)K4[2], (double)K4[3], (double)D5[0], (double)D5[1],
-                       (double)D5[2], (double)D5[3], (double)D5[4]};
-    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, kps, n, U, out);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, kps, n, undistort_args(K4, D5), out);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <vector>
 
+#include "frame_internal.h"
 #include "match_internal.h"
 #include "orbgpu_internal.h"
 
@@ -18,6 +19,8 @@ int launch_grid_only(hipStream_t st, const MatchArgs &A);
 int launch_shift_queries(hipStream_t st, int npairs, const orbgpu_keypoint *kps, const int32_t *n, int capacity, float du,
                          float dv, float th, const ScaleTab &sc, const float *b4, orbgpu_wquery *q);
 int launch_stereo(hipStream_t st, const StereoArgs &A);
+int launch_init_queries(hipStream_t st, const orbgpu_keypoint *kps1, int n1, const float *prev_xy, int window, orbgpu_wquery *q);
+int launch_init_update(hipStream_t st, const int32_t *matches12, int n1, const orbgpu_keypoint *kps2, float *prev_xy);
 int launch_distinctive(hipStream_t st, const uint8_t *d_desc, const int32_t *d_start, int npoints, int32_t *d_best_idx,
                        int32_t *d_best_median);
 int launch_undistort(hipStream_t st, const orbgpu_keypoint *kps, int n, const float *K4, const float *D5, orbgpu_keypoint *out);
@@ -315,7 +318,8 @@ static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orb
                       const int32_t *d_nq, int32_t q_cap, const orbgpu_keypoint *d_kps2, const uint8_t *d_desc2,
                       const float *d_uright2, const int32_t *d_n2, int32_t t_cap, const float *b4, const uint8_t *d_occ,
                       int32_t *d_assign, int32_t *d_qmatch, int32_t th_dist, float nnratio, int32_t ori, int32_t *d_nmatches,
-                      const int32_t *d_seg_start = nullptr, const int32_t *d_seg_index = nullptr, const MatchArgs *extra = nullptr)
+                      const int32_t *d_seg_start = nullptr, const int32_t *d_seg_index = nullptr, const MatchArgs *extra = nullptr,
+                      const int32_t *d_grid = nullptr)
 {
     if (npairs < 1 || q_cap < 1 || t_cap < 1 || t_cap > (1 << 20) || !(b4[2] > b4[0]) || !(b4[3] > b4[1])) {
         set_error("window matcher: invalid sizes or bounds");
@@ -333,6 +337,7 @@ static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orb
     A.occupied = d_occ; A.assign = d_assign; A.qmatch = d_qmatch; A.scratch = (int32_t *)m->scratch.p;
     A.th_dist = th_dist; A.nnratio = nnratio; A.check_orientation = ori; A.nmatches = d_nmatches;
     A.seg_start = d_seg_start; A.seg_index = d_seg_index;
+    A.grid = npairs == 1 ? d_grid : nullptr;
     if ((rc = m->stats.ensure((size_t)npairs * 16))) return rc;
     ORBGPU_HIP_CHECK(hipMemsetAsync(m->stats.p, 0, (size_t)npairs * 16, m->stream));
     A.stats = (int32_t *)m->stats.p;
@@ -369,22 +374,37 @@ int orbgpu_search_by_projection_batch_device(orbgpu_matcher *m, int32_t mode, in
                       d_occupied, d_assign, nullptr, th_dist, nnratio, check_orientation, d_nmatches);
 }
 
-// Host-pointer front end shared by SearchByProjection and SearchForInitialization.
+// Operands of a windowed call that are on the device already.
+struct WindowDev {
+    const orbgpu_frame *train = nullptr;   // the train side is this frame (keypoints, descriptors, uRight, grid)
+    const orbgpu_wquery *d_q = nullptr;    // the queries and their descriptors (both or neither)
+    const uint8_t *d_qdesc = nullptr;
+};
+
+// Front end shared by the windowed and segmented searches: host arrays are staged on the device, operands named in
+// `dev` are used where they lie.
 static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq,
                        const orbgpu_keypoint *kps2, const uint8_t *desc2, const float *uright2, int32_t n2, const float *b4,
                        const uint8_t *occupied, int32_t *assign, int32_t *qmatch, int32_t th_dist, float nnratio, int32_t ori,
                        int32_t *nmatches, const int32_t *seg_start = nullptr, const int32_t *seg_index = nullptr, int32_t nseg = 0,
-                       const MatchArgs *extra = nullptr)
+                       const MatchArgs *extra = nullptr, const WindowDev *dev = nullptr)
 {
     ORBGPU_HIP_CHECK(hipSetDevice(m->device));
     hipStream_t st = m->stream;
-    const int qc = nq > 0 ? nq : 1, tc = n2 > 0 ? n2 : 1;
+    const orbgpu_frame *train = dev ? dev->train : nullptr;
+    const bool dev_q = dev && dev->d_q;
+    // a frame's grid is laid out for the frame's capacity
+    const int qc = nq > 0 ? nq : 1, tc = train ? train->capacity : (n2 > 0 ? n2 : 1);
     int rc;
-    if ((rc = m->stage[0].ensure((size_t)qc * sizeof(orbgpu_wquery)))) return rc;
-    if ((rc = m->stage[1].ensure((size_t)qc * 32))) return rc;
-    if ((rc = m->stage[2].ensure((size_t)tc * sizeof(orbgpu_keypoint)))) return rc;
-    if ((rc = m->stage[3].ensure((size_t)tc * 32))) return rc;
-    if ((rc = m->stage[4].ensure((size_t)tc * 4))) return rc;
+    if (!dev_q) {
+        if ((rc = m->stage[0].ensure((size_t)qc * sizeof(orbgpu_wquery)))) return rc;
+        if ((rc = m->stage[1].ensure((size_t)qc * 32))) return rc;
+    }
+    if (!train) {
+        if ((rc = m->stage[2].ensure((size_t)tc * sizeof(orbgpu_keypoint)))) return rc;
+        if ((rc = m->stage[3].ensure((size_t)tc * 32))) return rc;
+        if ((rc = m->stage[4].ensure((size_t)tc * 4))) return rc;
+    }
     if ((rc = m->stage[5].ensure((size_t)tc))) return rc;
     if ((rc = m->stage[6].ensure((size_t)tc * 4))) return rc;
     if ((rc = m->stage[7].ensure((size_t)qc * 4))) return rc;
@@ -396,30 +416,43 @@ static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, 
         ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[9].p, seg_start, (size_t)(nseg + 1) * 4, hipMemcpyHostToDevice, st));
         if (nidx > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[10].p, seg_index, (size_t)nidx * 4, hipMemcpyHostToDevice, st));
     }
-    if (nq > 0) {
+    if (nq > 0 && !dev_q) {
         ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, q, (size_t)nq * sizeof(orbgpu_wquery), hipMemcpyHostToDevice, st));
         ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[1].p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     }
     if (n2 > 0) {
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[2].p, kps2, (size_t)n2 * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[3].p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
-        if (uright2) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[4].p, uright2, (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+        if (!train) {
+            ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[2].p, kps2, (size_t)n2 * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
+            ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[3].p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+            if (uright2) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[4].p, uright2, (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+        }
         if (occupied) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[5].p, occupied, (size_t)n2, hipMemcpyHostToDevice, st));
     }
     int32_t hc[4] = {nq, n2, 0, 0};
     ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[8].p, hc, 16, hipMemcpyHostToDevice, st));
     int32_t *dc = (int32_t *)m->stage[8].p;
-    rc = run_window(m, mode, 1, (const orbgpu_wquery *)m->stage[0].p, (const uint8_t *)m->stage[1].p, dc, qc,
-                    (const orbgpu_keypoint *)m->stage[2].p, (const uint8_t *)m->stage[3].p,
-                    uright2 ? (const float *)m->stage[4].p : nullptr, dc + 1, tc, b4, occupied ? (const uint8_t *)m->stage[5].p : nullptr,
+    const orbgpu_keypoint *d_k2 = train ? train->kps_un : (const orbgpu_keypoint *)m->stage[2].p;
+    const uint8_t *d_d2 = train ? train->desc : (const uint8_t *)m->stage[3].p;
+    const float *d_ur = !uright2 ? nullptr : train ? train->uright : (const float *)m->stage[4].p;
+    rc = run_window(m, mode, 1, dev_q ? dev->d_q : (const orbgpu_wquery *)m->stage[0].p, dev_q ? dev->d_qdesc : (const uint8_t *)m->stage[1].p,
+                    dc, qc, d_k2, d_d2, d_ur, dc + 1, tc, b4, occupied ? (const uint8_t *)m->stage[5].p : nullptr,
                     (int32_t *)m->stage[6].p, (int32_t *)m->stage[7].p, th_dist, nnratio, ori, dc + 2,
-                    seg_start ? (const int32_t *)m->stage[9].p : nullptr, seg_start ? (const int32_t *)m->stage[10].p : nullptr, extra);
+                    seg_start ? (const int32_t *)m->stage[9].p : nullptr, seg_start ? (const int32_t *)m->stage[10].p : nullptr, extra,
+                    train ? train->grid() : nullptr);
     if (rc) return rc;
     if (assign && n2 > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(assign, m->stage[6].p, (size_t)n2 * 4, hipMemcpyDeviceToHost, st));
     if (qmatch && nq > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(qmatch, m->stage[7].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_CHECK(hipMemcpyAsync(hc, dc, 16, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
     *nmatches = hc[2];
+    return ORBGPU_OK;
+}
+
+// A frame as the train side of a matcher call: built, and on the matcher's device.
+static int check_train_frame(const char *who, const orbgpu_matcher *m, const orbgpu_frame *f)
+{
+    if (!f || !f->built) { set_error("%s: the frame has not been built", who); return ORBGPU_E_INVALID; }
+    if (f->device != m->device) { set_error("%s: the frame lives on device %d, the matcher on %d", who, f->device, m->device); return ORBGPU_E_INVALID; }
     return ORBGPU_OK;
 }
 
@@ -817,6 +850,143 @@ int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extrac
         }
     }
     *nvalid = valid;
+    return ORBGPU_OK;
+}
+
+// ---- the same searches with a device-resident frame as the train side ------------------------------------------
+// The frame's undistorted keypoints, descriptors, uRight and grid are read where orbgpu_frame_build_* left them.
+// When the matcher carries a one-shot grid geometry (a KeyFrame's truncated bounds), its build origin must be the
+// frame's: the frame's grid is used as built.
+
+int orbgpu_search_by_projection_frame(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq,
+                                      const orbgpu_frame *train, const uint8_t *occupied, int32_t *assign, int32_t th_dist,
+                                      float nnratio, int32_t check_orientation, int32_t *nmatches)
+{
+    if (!m || mode < 0 || mode > 2 || nq < 0 || (nq > 0 && (!q || !qdesc)) || !nmatches || !train || (train->n > 0 && !assign)) {
+        set_error("orbgpu_search_by_projection_frame: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    int rc = check_train_frame("orbgpu_search_by_projection_frame", m, train);
+    if (rc) return rc;
+    WindowDev dev;
+    dev.train = train;
+    return window_host(m, mode, q, qdesc, nq, nullptr, nullptr, train->uright, train->n, train->bounds4, occupied, assign, nullptr,
+                       th_dist, nnratio, check_orientation, nmatches, nullptr, nullptr, 0, nullptr, &dev);
+}
+
+int orbgpu_search_in_area_frame(orbgpu_matcher *m, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq, const orbgpu_frame *train,
+                                const float *inv_sigma2, int32_t nlevels, int32_t chi2_gate, int32_t th_dist, int32_t *qmatch,
+                                int32_t *nmatches)
+{
+    if (!m || nq < 0 || (nq > 0 && (!q || !qdesc || !qmatch)) || !train || !nmatches ||
+        (chi2_gate && (!inv_sigma2 || nlevels < 1 || nlevels > ORBGPU_MAX_LEVELS))) {
+        set_error("orbgpu_search_in_area_frame: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    int rc = check_train_frame("orbgpu_search_in_area_frame", m, train);
+    if (rc) return rc;
+    MatchArgs X;
+    memset(&X, 0, sizeof(X));
+    X.chi2_gate = chi2_gate ? 1 : 0;
+    if (chi2_gate) {
+        if (nlevels < train->nlevels) {
+            set_error("orbgpu_search_in_area_frame: %d levels given, the frame's keypoints span %d", nlevels, train->nlevels);
+            return ORBGPU_E_INVALID;
+        }
+        for (int l = 0; l < nlevels; l++) X.inv_sigma2.s[l] = inv_sigma2[l];
+    }
+    WindowDev dev;
+    dev.train = train;
+    return window_host(m, 6, q, qdesc, nq, nullptr, nullptr, chi2_gate ? train->uright : nullptr, train->n, train->bounds4, nullptr,
+                       nullptr, qmatch, th_dist, 1.0f, 0, nmatches, nullptr, nullptr, 0, &X, &dev);
+}
+
+int orbgpu_search_by_bow_frame(orbgpu_matcher *m, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq, const orbgpu_frame *train,
+                               const int32_t *seg_start, const int32_t *seg_index, int32_t nseg, const uint8_t *excluded,
+                               int32_t th_dist, float nnratio, int32_t check_orientation, int32_t *assign, int32_t *qmatch,
+                               int32_t *nmatches)
+{
+    if (!m || nq < 0 || nseg < 0 || (nq > 0 && (!q || !qdesc)) || !train || !seg_start || (nseg > 0 && !seg_index) || !nmatches ||
+        (train->n > 0 && !assign)) {
+        set_error("orbgpu_search_by_bow_frame: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    int rc = check_train_frame("orbgpu_search_by_bow_frame", m, train);
+    if (rc) return rc;
+    if ((rc = check_segments("orbgpu_search_by_bow_frame", q, nq, train->n, seg_start, seg_index, nseg))) return rc;
+    const float b4[4] = {0.f, 0.f, 1.f, 1.f};
+    WindowDev dev;
+    dev.train = train;
+    return window_host(m, 4, q, qdesc, nq, nullptr, nullptr, nullptr, train->n, b4, excluded, assign, qmatch, th_dist, nnratio,
+                       check_orientation, nmatches, seg_start, seg_index, nseg, nullptr, &dev);
+}
+
+int orbgpu_search_for_triangulation_frame(orbgpu_matcher *m, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq,
+                                          const orbgpu_frame *train, int32_t use_uright, const int32_t *seg_start,
+                                          const int32_t *seg_index, int32_t nseg, const uint8_t *excluded, const float *F12, float ex,
+                                          float ey, const float *scale2, const float *sigma2, int32_t nlevels, int32_t only_stereo,
+                                          int32_t check_orientation, int32_t *qmatch, int32_t *nmatches)
+{
+    if (!m || nq < 0 || nseg < 0 || (nq > 0 && (!q || !qdesc || !qmatch)) || !train || !seg_start || (nseg > 0 && !seg_index) || !F12 ||
+        !scale2 || !sigma2 || nlevels < 1 || nlevels > ORBGPU_MAX_LEVELS || !nmatches) {
+        set_error("orbgpu_search_for_triangulation_frame: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    int rc = check_train_frame("orbgpu_search_for_triangulation_frame", m, train);
+    if (rc) return rc;
+    if ((rc = check_segments("orbgpu_search_for_triangulation_frame", q, nq, train->n, seg_start, seg_index, nseg))) return rc;
+    if (nlevels < train->nlevels) {
+        set_error("orbgpu_search_for_triangulation_frame: %d levels given, the frame's keypoints span %d", nlevels, train->nlevels);
+        return ORBGPU_E_INVALID;
+    }
+    MatchArgs X;
+    memset(&X, 0, sizeof(X));
+    for (int k = 0; k < 9; k++) X.F12[k] = F12[k];
+    X.ex = ex; X.ey = ey; X.only_stereo = only_stereo;
+    for (int l = 0; l < nlevels; l++) { X.scale2.s[l] = scale2[l]; X.sigma2.s[l] = sigma2[l]; }
+    const float b4[4] = {0.f, 0.f, 1.f, 1.f};
+    WindowDev dev;
+    dev.train = train;
+    return window_host(m, 5, q, qdesc, nq, nullptr, nullptr, use_uright ? train->uright : nullptr, train->n, b4, excluded, nullptr, qmatch,
+                       ORBGPU_TH_LOW, 1.0f, check_orientation, nmatches, seg_start, seg_index, nseg, &X, &dev);
+}
+
+// SearchForInitialization between two frames: the queries are made on the device from frame 1's undistorted
+// keypoints and the caller's vbPrevMatched, and vbPrevMatched is updated there too (:566-568).
+int orbgpu_search_for_initialization_frames(orbgpu_matcher *m, const orbgpu_frame *f1, const orbgpu_frame *f2, float *prev_matched_xy,
+                                            int32_t *matches12, int32_t window_size, float nnratio, int32_t check_orientation,
+                                            int32_t *nmatches)
+{
+    if (!m || !f1 || !f2 || !nmatches || (f1->n > 0 && (!prev_matched_xy || !matches12))) {
+        set_error("orbgpu_search_for_initialization_frames: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    int rc = check_train_frame("orbgpu_search_for_initialization_frames", m, f1);
+    if (rc) return rc;
+    if ((rc = check_train_frame("orbgpu_search_for_initialization_frames", m, f2))) return rc;
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    const int n1 = f1->n;
+    if ((rc = m->stage[0].ensure((size_t)(n1 > 0 ? n1 : 1) * sizeof(orbgpu_wquery)))) return rc;
+    if ((rc = m->stage[11].ensure((size_t)(n1 > 0 ? n1 : 1) * 8))) return rc;
+    if (n1 > 0) {
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[11].p, prev_matched_xy, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
+        if ((rc = launch_init_queries(st, f1->kps_un, n1, (const float *)m->stage[11].p, window_size, (orbgpu_wquery *)m->stage[0].p)))
+            return rc;
+    }
+    WindowDev dev;
+    dev.train = f2;
+    dev.d_q = (const orbgpu_wquery *)m->stage[0].p;
+    dev.d_qdesc = f1->desc;
+    // window_host downloads matches12 and waits; the update of vbPrevMatched then reads the device copy of matches12
+    rc = window_host(m, 3, nullptr, nullptr, n1, nullptr, nullptr, nullptr, f2->n, f2->bounds4, nullptr, nullptr, matches12, ORBGPU_TH_LOW,
+                     nnratio, check_orientation, nmatches, nullptr, nullptr, 0, nullptr, &dev);
+    if (rc) return rc;
+    if (n1 > 0) {
+        if ((rc = launch_init_update(st, (const int32_t *)m->stage[7].p, n1, f2->kps_un, (float *)m->stage[11].p))) return rc;
+        ORBGPU_HIP_CHECK(hipMemcpyAsync(prev_matched_xy, m->stage[11].p, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
+        ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    }
     return ORBGPU_OK;
 }
 

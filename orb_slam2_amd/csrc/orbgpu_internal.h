@@ -89,6 +89,22 @@ __host__ __device__ inline int32_t blur_tiled_off(int32_t pitch, int32_t x, int3
 
 void set_error(const char *fmt, ...);
 
+// Where the host-image path of an extractor handle leaves its results (extractor_api.hip).
+struct HostExtraction {
+    orbgpu_keypoint *d_kps;   // device, frame f at + f * cap; valid until the handle's next call
+    uint8_t *d_desc;
+    int32_t *d_counts;
+    const orbgpu_keypoint *h_kps;  // the handle's page-locked block, valid once `stream` has been waited for
+    const uint8_t *h_desc;
+    const int32_t *h_counts, *h_status;
+    int cap;                  // entries per frame in all of the above
+    hipStream_t stream;
+};
+int extract_host_enqueue(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h, int32_t stride,
+                         HostExtraction *X);
+int extract_host_begin(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h, int32_t stride,
+                       HostExtraction *X);
+
 // Grids are (blocks, frames).  Workgroups are dealt to the 8 XCDs round-robin in
 // linear order; for batches of 8 or more frames the grid is (8 * blocks, frame
 // groups of 8) instead, so that all blocks of a frame run on one XCD and share

@@ -122,6 +122,12 @@ __device__ __forceinline__ PairCtx make_ctx(const MatchArgs &A, int pair)
     P.sd_cur = P.sd0;
     P.nxt = s;                         s += A.q_cap;
     P.full = s;
+    if (A.grid) {  // the train frame's own grid (built by k_grid_build with the same t_cap)
+        int32_t *g = const_cast<int32_t *>(A.grid);
+        P.cell_start = g;
+        P.grec = (int4 *)(g + 3080);
+        P.gdesc = (uint32_t *)(g + 3080 + 4 * (size_t)A.t_cap);
+    }
     P.invW = A.invW;
     P.invH = A.invH;
     return P;
@@ -1004,9 +1010,55 @@ __global__ __launch_bounds__(256) void k_shift_queries(const orbgpu_keypoint *__
     q[(size_t)pair * capacity + i] = w;
 }
 
+// SearchForInitialization queries (src/ORBmatcher.cc:444-453): a window around vbPrevMatched for every level-0
+// keypoint of frame 1; and the update of vbPrevMatched with the matched keypoints of frame 2 (:566-568).
+__global__ __launch_bounds__(256) void k_init_queries(const orbgpu_keypoint *__restrict__ kps1, int n1, const float *__restrict__ prev_xy,
+                                                      int window, orbgpu_wquery *__restrict__ q)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n1) return;
+    const orbgpu_keypoint kp = kps1[i];
+    orbgpu_wquery w;
+    w.u = prev_xy[2 * i];
+    w.v = prev_xy[2 * i + 1];
+    w.r = (float)window;
+    w.minLevel = kp.octave;
+    w.maxLevel = kp.octave;
+    w.angle = kp.angle;
+    w.ur = -1.0f;
+    w.flags = kp.octave > 0 ? 0 : 1;
+    q[i] = w;
+}
+
+__global__ __launch_bounds__(256) void k_init_update(const int32_t *__restrict__ matches12, int n1, const orbgpu_keypoint *__restrict__ kps2,
+                                                     float *__restrict__ prev_xy)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n1) return;
+    const int t = matches12[i];
+    if (t >= 0) {
+        prev_xy[2 * i] = kps2[t].x;
+        prev_xy[2 * i + 1] = kps2[t].y;
+    }
+}
+
+int launch_init_queries(hipStream_t st, const orbgpu_keypoint *kps1, int n1, const float *prev_xy, int window, orbgpu_wquery *q)
+{
+    hipLaunchKernelGGL(k_init_queries, dim3((n1 + 255) / 256), dim3(256), 0, st, kps1, n1, prev_xy, window, q);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+int launch_init_update(hipStream_t st, const int32_t *matches12, int n1, const orbgpu_keypoint *kps2, float *prev_xy)
+{
+    hipLaunchKernelGGL(k_init_update, dim3((n1 + 255) / 256), dim3(256), 0, st, matches12, n1, kps2, prev_xy);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
 int launch_match_window(hipStream_t st, const MatchArgs &A, int npairs)
 {
-    if (A.mode != 4 && A.mode != 5) hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
+    if (A.mode != 4 && A.mode != 5 && !A.grid) hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(1024), 0, st, A);
     // a lane per query pays once there are enough queries to fill the chip; below that the half-wave scan is quicker
     if (A.mode == 4 || A.mode == 5 || (int64_t)A.q_cap * npairs < 65536)
         hipLaunchKernelGGL(k_window_topk, dim3((A.q_cap + 7) / 8, npairs), dim3(256), 0, st, A);

@@ -6,10 +6,12 @@
 
 #include <cmath>
 #include <map>
+#include <memory>
 #include <set>
 #include <type_traits>
 #include <vector>
 
+#include "FrameDevice.h"   // ORB_SLAM2::DeviceFrame
 #include "ORBextractor.h"  // orbcv::KeyPoint, orbcv::Mat (8-bit), orbcv::Point2f
 
 namespace slamtest {
@@ -41,6 +43,7 @@ struct Frame {
     float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
     int mnScaleLevels = 0;
     float mfLogScaleFactor = 0;
+    std::shared_ptr<ORB_SLAM2::DeviceFrame> mpDeviceFrame;  // null: the matchers are given the host arrays
 };
 
 struct KeyFrame {
@@ -58,6 +61,7 @@ struct KeyFrame {
     float mfLogScaleFactor = 0;
     FMat Tcw;  // 4x4
     std::vector<MapPoint *> mvpMapPoints;
+    std::shared_ptr<ORB_SLAM2::DeviceFrame> mpDeviceFrame;  // the handle of the Frame the KeyFrame was made from
 
     std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
     std::set<MapPoint *> GetMapPoints()

@@ -2,7 +2,9 @@
 // sequential CPU restatements (oracle/orb_oracle_frames.h) on seeded synthetic scenes: a cloud of 3-D points seen
 // from two poses, keypoints at the projections plus clutter, descriptors that are noisy copies of a per-point code.
 // Every scenario builds the same scene twice (one copy per implementation), runs both and compares every container
-// the reference writes.  Prints one line per scenario; exit status 0 only if all agree.
+// the reference writes.  All scenarios run twice: with plain Frames / KeyFrames (the matchers upload their arrays) and
+// with Frames that carry a device-resident copy (mpDeviceFrame: the matchers read the train side on the GPU).
+// Prints one line per scenario; exit status 0 only if all agree.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -149,6 +151,8 @@ static void make_view(Scene &S, const std::vector<WorldPoint> &W, View &V, float
     }
 }
 
+static bool g_device_frames = false;  // the scenes' Frames and KeyFrames carry a DeviceFrame
+
 static void fill_frame(Scene &S, const View &V, Frame &F)
 {
     F.N = (int)V.keys.size();
@@ -164,6 +168,13 @@ static void fill_frame(Scene &S, const View &V, Frame &F)
     F.fx = S.fx; F.fy = S.fy; F.cx = S.cx; F.cy = S.cy; F.mbf = S.bf; F.mb = S.bf / S.fx;
     F.mnMinX = S.bounds[0]; F.mnMinY = S.bounds[1]; F.mnMaxX = S.bounds[2]; F.mnMaxY = S.bounds[3];
     F.mnScaleLevels = 8; F.mfLogScaleFactor = logf(1.2f);
+    if (g_device_frames) {
+        F.mpDeviceFrame = std::make_shared<ORB_SLAM2::DeviceFrame>(F.N > 0 ? F.N : 1);
+        if (F.mpDeviceFrame->Upload(F.mvKeys.data(), F.mvKeysUn.data(), F.mDescriptors.data, F.mvuRight.data(), nullptr, F.N, 8, S.bounds) != F.N) {
+            fprintf(stderr, "DeviceFrame::Upload: %s\n", F.mpDeviceFrame->LastError().c_str());
+            exit(2);
+        }
+    }
 }
 
 static void fill_keyframe(Scene &S, const View &V, const Frame &F, KeyFrame &K)
@@ -183,6 +194,7 @@ static void fill_keyframe(Scene &S, const View &V, const Frame &F, KeyFrame &K)
     K.Ow = FMat(3, 1);
     for (int i = 0; i < 3; i++) K.Ow.at<float>(i, 0) = -(V.R[i] * V.t[0] + V.R[3 + i] * V.t[1] + V.R[6 + i] * V.t[2]);
     K.mvpMapPoints.assign(K.N, nullptr);
+    K.mpDeviceFrame = F.mpDeviceFrame;  // a KeyFrame keeps the arrays of its Frame (src/KeyFrame.cc:37-52)
 }
 
 static std::unique_ptr<Scene> build(const Cfg &cfg)
@@ -257,8 +269,9 @@ static std::vector<int> ids(const std::vector<MapPoint *> &v)
 }
 
 static int g_fail = 0;
-static void report(const std::string &name, bool same, int n_gpu, int n_cpu, int min_expected, const std::string &extra = "")
+static void report(const std::string &name0, bool same, int n_gpu, int n_cpu, int min_expected, const std::string &extra = "")
 {
+    const std::string name = name0 + (g_device_frames ? " [device frames]" : "");
     const bool ok = same && n_gpu == n_cpu && n_gpu >= min_expected;
     printf("%-44s gpu %5d  cpu %5d  %s %s\n", name.c_str(), n_gpu, n_cpu, ok ? "OK" : "FAIL", extra.c_str());
     if (!ok) g_fail++;
@@ -342,13 +355,9 @@ static void relative(const Scene &S, FMat &R12, FMat &t12, FMat &F12)
         for (int j = 0; j < 3; j++) { double a = 0; for (int k = 0; k < 3; k++) a += M[3 * i + k] * Ki[3 * k + j]; F12.d[3 * i + j] = (float)a; }
 }
 
-int main()
+static void run_scenarios()
 {
     using ORB_SLAM2::ORBmatcher;
-    {
-        ORBmatcher probe;
-        if (!probe.LastError().empty()) { fprintf(stderr, "no GPU matcher: %s\n", probe.LastError().c_str()); return 2; }
-    }
     char name[128];
 
     // 1. SearchByProjection(Frame&, vector<MapPoint*>&, th)
@@ -618,6 +627,18 @@ int main()
         m3 = m1;
         report("ComputeThreeMaxima + copies", same && m2.LastError().empty() && m3.LastError().empty(), 1, 1, 1);
     }
+}
+
+int main()
+{
+    {
+        ORB_SLAM2::ORBmatcher probe;
+        if (!probe.LastError().empty()) { fprintf(stderr, "no GPU matcher: %s\n", probe.LastError().c_str()); return 2; }
+    }
+    g_device_frames = false;
+    run_scenarios();
+    g_device_frames = true;
+    run_scenarios();
     printf("%s\n", g_fail ? "FAILED" : "ALL OK");
     return g_fail ? 1 : 0;
 }

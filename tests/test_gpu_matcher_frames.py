@@ -37,6 +37,9 @@ def test_all_eleven_overloads_match_the_oracle():
     for name in SCENARIOS:
         hits = [ln for ln in lines if ln.startswith(name)]
         assert hits and all(" OK" in ln for ln in hits), name
+        # every scenario also ran with Frames / KeyFrames that carry a device-resident copy of their arrays
+        dev = [ln for ln in hits if "[device frames]" in ln]
+        assert len(dev) * 2 == len(hits), name
 
 
 @pytest.mark.gpu
@@ -48,3 +51,5 @@ def test_the_comparison_notices_a_wrong_keyframe_grid_origin():
     assert r.returncode == 1, r.stdout + r.stderr
     bad = [ln for ln in r.stdout.splitlines() if " FAIL" in ln]
     assert bad and all(" dist" in ln.split("gpu")[0] for ln in bad), r.stdout
+    # a device-resident frame carries the grid its Frame built: the wrong origin cannot reach it
+    assert not any("[device frames]" in ln for ln in bad), r.stdout
