@@ -17,6 +17,11 @@ namespace orbgpu {
 // Pyramid (ORBextractor::ComputePyramid, src/ORBextractor.cc:1528-1592)
 // ---------------------------------------------------------------------------
 // Store pixels x0 .. x0+n-1 of one row (packed little-endian in v[], NW words).
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits until the wave's global stores have
+// been acknowledged; where the data the other waves need is in LDS and the global stores are results nobody in the
+// kernel reads back, that wait (about a microsecond per barrier for a lone workgroup) buys nothing.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int NW>
 __device__ __forceinline__ void store_row_span(uint8_t *row, int x0, int n, const uint32_t (&v)[NW])
 {
@@ -176,6 +181,138 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
             *reinterpret_cast<uint16_t *>(q) = v;
             if (ym != y) *reinterpret_cast<uint16_t *>(qm) = v;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Levels l_first .. l_last in ONE launch, for a single frame or a few: a frame's pyramid is a chain of dependent
+// resizes, and with a handful of small launches the chain costs more in launch-to-launch gaps than in arithmetic.
+// A workgroup owns a kFW x kFH tile of the LAST level and works backwards to the region of every earlier level
+// that the tile depends on (the taps of the taps ...), then produces those regions level by level in LDS, each from
+// the one before; the first from level l_first - 1 in global memory.  Every region is also written to the level's
+// plane.  Regions of neighbouring tiles overlap: the overlap is computed twice, by the same integer arithmetic, and
+// stored twice with equal bytes.  Together the regions cover every level: a level's columns (rows) are all tapped by
+// the next level's while the scale step is at most 2, the regions of edge tiles are extended to the level's edge,
+// and the launcher falls back to one launch per level for other geometries.
+// ---------------------------------------------------------------------------
+// LDS: column entries {tap, next tap (both relative to the source region), a0, a1} and row entries {upper / lower
+// source row relative to the source region, b0, b1, row of the reflect-101 image, row} of every level's region, then
+// two region buffers used alternately; the first holds the staged region of level l_first - 1.  The regions come
+// from the host's table (extractor_api.hip, set_geometry).
+__global__ __launch_bounds__(1024) void k_pyr_fused(uint8_t *__restrict__ pyr, Geom G, int l_first, int l_last, const XTab *__restrict__ xtab,
+                                                    const YTab *__restrict__ ytab, const FuseRegion *__restrict__ fuse_tab, int lds_entries,
+                                                    int lds_half)
+{
+    extern __shared__ __align__(16) uint8_t fuse_lds[];
+    uint2 *xe = reinterpret_cast<uint2 *>(fuse_lds);                                  // [lds_entries]
+    uint4 *ye = reinterpret_cast<uint4 *>(fuse_lds + (size_t)lds_entries * 8);          // [lds_entries]
+    uint8_t *bufs = fuse_lds + (size_t)lds_entries * 24;                                // 2 x lds_half
+    __shared__ FuseRegion R[ORBGPU_MAX_LEVELS];
+    __shared__ int eoff[ORBGPU_MAX_LEVELS];        // first column / row entry of a level (rows follow the same numbering in ye)
+    __shared__ int tfirst[ORBGPU_MAX_LEVELS + 1];  // running count of table entries (columns + rows) before a level
+    const int tid = threadIdx.x, nt = blockDim.x, f = blockIdx.y;
+    if (tid < G.nlevels) R[tid] = fuse_tab[(size_t)blockIdx.x * G.nlevels + tid];
+    __syncthreads();
+    if (tid == 0) {
+        int ne = 0, nte = 0;
+        for (int l = l_last; l >= l_first; l--) {
+            const FuseRegion r = R[l];
+            eoff[l] = ne;
+            tfirst[l] = nte;
+            ne += max(r.x1 - r.x0 + 1, r.y1 - r.y0 + 1);
+            nte += (r.x1 - r.x0 + 1) + (r.y1 - r.y0 + 1);
+        }
+        tfirst[l_first - 1] = nte;  // total
+    }
+    __syncthreads();
+    uint8_t *base = pyr + (int64_t)f * G.pyr_frame_bytes;
+    // stage the tables of every level and the region of the source level: all loads first, then the LDS writes, so
+    // that the workgroup (the only one on its CU) waits for global memory once
+    {
+        constexpr int kTE = 1, kSD = 2;  // table entries / source dwords per thread and batch
+        const int T = tfirst[l_first - 1];
+        const LevelGeom &gs0 = G.lv[l_first - 1];
+        const FuseRegion q0 = R[l_first - 1];
+        const int qdw = (q0.x1 - q0.x0 + 1) >> 2, nsd = qdw * (q0.y1 - q0.y0 + 1);
+        const uint8_t *S0 = base + interior_off(gs0) + (int64_t)q0.y0 * gs0.pitch + q0.x0;
+        const float inv_qdw = __fdiv_rn(1.0f, (float)qdw);
+        for (int t0 = 0, s0 = 0; t0 < T || s0 < nsd; t0 += kTE * nt, s0 += kSD * nt) {
+            XTab tx_[kTE];
+            YTab ty_[kTE];
+            int lv_[kTE], k_[kTE];
+            uint32_t sd_[kSD];
+#pragma unroll
+            for (int u = 0; u < kTE; u++) {
+                const int e = t0 + u * nt + tid;
+                lv_[u] = -1;
+                if (e < T) {
+                    int l = l_last;
+                    while (l > l_first && e >= tfirst[l - 1]) l--;  // levels are numbered downwards in tfirst
+                    const FuseRegion r = R[l];
+                    const int k = e - tfirst[l], rw = r.x1 - r.x0 + 1;
+                    lv_[u] = l; k_[u] = k;
+                    if (k < rw) tx_[u] = xtab[G.lv[l].xtab_off + r.x0 + k];
+                    else ty_[u] = ytab[G.lv[l].ytab_off + r.y0 + k - rw];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kSD; u++) {
+                const int i = s0 + u * nt + tid;
+                if (i < nsd) {
+                    const int ry = (int)__fmul_rn((float)i + 0.5f, inv_qdw), rx = i - ry * qdw;  // exact: i < 2^16
+                    sd_[u] = *reinterpret_cast<const uint32_t *>(S0 + (int64_t)ry * gs0.pitch + 4 * rx);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kTE; u++) {
+                const int l = lv_[u];
+                if (l < 0) continue;
+                const FuseRegion r = R[l], q = R[l - 1];
+                const int rw = r.x1 - r.x0 + 1, k = k_[u];
+                if (k < rw) {
+                    const XTab t = tx_[u];
+                    // the right tap is the next byte: its weight is 0 where the reference clamps it
+                    xe[eoff[l] + k] = make_uint2((uint32_t)(t.sx - q.x0) | ((uint32_t)(min(t.sx + 1, G.lv[l - 1].w - 1) - q.x0) << 16),
+                                                 (uint32_t)(uint16_t)t.a0 | ((uint32_t)(uint16_t)t.a1 << 16));
+                } else {
+                    const YTab v = ty_[u];
+                    ye[eoff[l] + k - rw] = make_uint4((uint32_t)(v.sy0 - q.y0) | ((uint32_t)(v.sy1 - q.y0) << 16),
+                                                      (uint32_t)(uint16_t)v.b0 | ((uint32_t)(uint16_t)v.b1 << 16),
+                                                      (uint32_t)((v.pad & 0xFFFF) - 32), (uint32_t)(r.y0 + k - rw));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kSD; u++) {
+                const int i = s0 + u * nt + tid;
+                if (i < nsd) reinterpret_cast<uint32_t *>(bufs)[i] = sd_[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = l_first; l <= l_last; l++) {
+        const LevelGeom &gd = G.lv[l];
+        const FuseRegion r = R[l], q = R[l - 1];
+        const int rw = r.x1 - r.x0 + 1, rh = r.y1 - r.y0 + 1, sp = q.x1 - q.x0 + 1, e0 = eoff[l];
+        const uint8_t *S = bufs + ((l - l_first) & 1 ? lds_half : 0);
+        uint8_t *Dl = bufs + ((l - l_first) & 1 ? 0 : lds_half);
+        uint8_t *Dg = base + interior_off(gd) + r.x0;
+        const float inv_rw = __fdiv_rn(1.0f, (float)rw);
+        for (int i = tid; i < rw * rh; i += nt) {
+            const int ry = (int)__fmul_rn((float)i + 0.5f, inv_rw), rx = i - ry * rw;  // exact: i < 2^16, rw < 2^9
+            const uint2 cx = xe[e0 + rx];
+            const uint4 cy = ye[e0 + ry];
+            const int c0 = (int)(cx.x & 0xFFFF), c1 = (int)(cx.x >> 16);
+            const int a0 = (int16_t)(cx.y & 0xFFFF), a1 = (int16_t)(cx.y >> 16);
+            const int b0 = (int16_t)(cy.y & 0xFFFF), b1 = (int16_t)(cy.y >> 16);
+            const uint8_t *A = S + (int)(cy.x & 0xFFFF) * sp, *B = S + (int)(cy.x >> 16) * sp;
+            const int hA = (A[c0] * a0 + A[c1] * a1) >> 4, hB = (B[c0] * a0 + B[c1] * a1) >> 4;
+            const uint8_t p = (uint8_t)((((b0 * hA) >> 16) + ((b1 * hB) >> 16) + 2) >> 2);
+            if (l < l_last) Dl[i] = p;
+            const int y = (int)cy.w, ym = (int)cy.z;  // the row and its reflect-101 image in the halo rows, if it has one
+            Dg[y * gd.pitch + rx] = p;
+            if (ym != y) Dg[ym * gd.pitch + rx] = p;
+        }
+        lds_barrier();  // the next level reads this one from LDS; nothing here reads the planes back
     }
 }
 
@@ -720,7 +857,8 @@ __device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__re
                                              const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,
                                              int32_t *scratch, uint32_t *__restrict__ sel,
                                              int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,
-                                             int32_t *__restrict__ status, int keys_cap, int lds_nodes, int dyn_coff_off)
+                                             int32_t *__restrict__ status, int keys_cap, int lds_nodes, int dyn_coff_off,
+                                             int pts_cap, int dyn_pts_off)
 {
     // dynamic LDS: keys_cap 64-bit sort keys, then (lds_nodes != 0) the node
     // arrays and per-node work lists of this level -- keeping them on chip takes
@@ -768,6 +906,19 @@ __device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__re
     const int nCells = g.nCols * g.nRows;
     const int32_t *cc = cell_counts + (int64_t)f * G.total_cells + g.cell_off;
     const uint32_t *sl = slots + (int64_t)f * G.slot_frame_u32 + g.slot_off;
+    uint32_t *const gathered = c.buf0;  // the gathered candidates are also kept in global memory (orbgpu_debug_level_candidates)
+    if (pts_cap > 0) {
+        // a level whose candidates fit keeps both candidate buffers in LDS: every subdivision round reads and
+        // re-partitions the points, and in global memory each of those steps is a dependent round trip
+        int mine = 0;
+        for (int ci = tid; ci < nCells; ci += nt) mine += cc[ci];
+        int total;
+        (void)block_scan_excl(mine, &total, scan_lds);
+        if (total <= pts_cap) {
+            c.buf0 = reinterpret_cast<uint32_t *>(dyn_lds + dyn_pts_off);
+            c.buf1 = c.buf0 + pts_cap;
+        }
+    }
     int M = 0;
     for (int b = 0; b < nCells; b += nt) {
         const int ci = b + tid;
@@ -784,7 +935,9 @@ __device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__re
                 const int mid = (lo + hi + 1) >> 1;
                 if (coff[mid] <= j) lo = mid; else hi = mid - 1;
             }
-            c.buf0[M + j] = sl[(int64_t)(b + lo) * g.cell_cap + (j - coff[lo])];
+            const uint32_t v = sl[(int64_t)(b + lo) * g.cell_cap + (j - coff[lo])];
+            c.buf0[M + j] = v;
+            if (c.buf0 != gathered) gathered[M + j] = v;
         }
         __syncthreads();
         M += total;
@@ -962,16 +1115,17 @@ __device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__re
 #define OCTREE_ARGS                                                                                                          \
     Geom G, const uint32_t *__restrict__ slots, const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,       \
         int32_t *scratch, uint32_t *__restrict__ sel, int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,     \
-        int32_t *__restrict__ status, int keys_cap, int lds_nodes, int dyn_coff_off
-// one frame: a few 1024-thread workgroups
+        int32_t *__restrict__ status, int keys_cap, int lds_nodes, int dyn_coff_off, int pts_cap, int dyn_pts_off
+// one frame: a few 1024-thread workgroups, each with most of a CU's LDS (candidate buffers included)
 __global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
 {
-    octree_level(G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, dyn_coff_off);
+    octree_level(G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, dyn_coff_off, pts_cap,
+                 dyn_pts_off);
 }
 // a batch: 256-thread workgroups, registers capped so that eight of them share a CU
 __global__ __launch_bounds__(256, 8) void k_octree_batch(OCTREE_ARGS)
 {
-    octree_level(G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, dyn_coff_off);
+    octree_level(G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, dyn_coff_off, 0, 0);
 }
 #undef OCTREE_ARGS
 
@@ -1404,7 +1558,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 // host-side launchers
 // ---------------------------------------------------------------------------
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
-                   const Geom &G_, const XTab *xtab, const YTab *ytab)
+                   const Geom &G_, const XTab *xtab, const YTab *ytab, const FuseArgs *fuse)
 {
     // the XCD-pinned frame mapping (nimg >= 8) pays off for the kernels that re-read shared rows
     // (resize, blur, describe); the streaming ones keep the plain mapping (nimg = 0)
@@ -1412,6 +1566,15 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     G.nimg = nimg;
     const LevelGeom &g0 = G.lv[0];
     hipLaunchKernelGGL(k_pyr_copy0, dim3((((g0.w + 15) / 16) * g0.h + 255) / 256, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G_);
+    // a few frames: all levels above 0 in one launch (k_pyr_fused) when the host could tabulate the regions
+    if (nimg <= 4 && G.nlevels > 1 && fuse && fuse->tab) {
+        const LevelGeom &gl = G.lv[G.nlevels - 1];
+        const size_t lds = (size_t)fuse->lds_entries * 24 + 2 * (size_t)fuse->lds_half;
+        hipLaunchKernelGGL(k_pyr_fused, dim3(((gl.w + kFW - 1) / kFW) * ((gl.h + kFH - 1) / kFH), nimg), dim3(1024), lds, st, pyr, G, 1,
+                           G.nlevels - 1, xtab, ytab, fuse->tab, fuse->lds_entries, fuse->lds_half);
+        ORBGPU_HIP_CHECK(hipGetLastError());
+        return ORBGPU_OK;
+    }
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
         hipLaunchKernelGGL(k_pyr_resize, frame_grid(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), nimg), dim3(256),
@@ -1489,13 +1652,33 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several
     const int threads = nimg * G.nlevels >= 256 ? 256 : 1024;
     const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
-    const size_t dyn = coff_off + (size_t)(threads + 1) * 4;
-    if (threads == 256)
+    size_t dyn = coff_off + (size_t)(threads + 1) * 4;
+    if (nimg * G.nlevels >= 256) {
         hipLaunchKernelGGL(k_octree_batch, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch,
-                           sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off);
-    else
+                           sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, 0, 0);
+    } else {
+        // the two candidate buffers of a level in LDS too, as far as 144 KiB go (a workgroup may use the whole CU's)
+        const size_t pts_off = (dyn + 15) & ~(size_t)15, budget = 144 * 1024;
+        int maxcand = 0;
+        for (int l = 0; l < G.nlevels; l++) maxcand = G.lv[l].cand_cap > maxcand ? G.lv[l].cand_cap : maxcand;
+        int pts_cap = pts_off + 64 < budget ? (int)((budget - pts_off) / 8) : 0;
+        if (pts_cap > maxcand) pts_cap = maxcand;
+        pts_cap &= ~3;
+        if (pts_cap < 256) pts_cap = 0;
+        if (pts_cap) dyn = pts_off + (size_t)pts_cap * 8;
+        static size_t granted = 64 * 1024;  // dynamic LDS beyond 64 KiB is asked for once
+        if (dyn > granted) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget + 8192) == hipSuccess) {
+                granted = 160 * 1024;
+            } else {
+                (void)hipGetLastError();
+                pts_cap = 0;
+                dyn = coff_off + (size_t)(threads + 1) * 4;
+            }
+        }
         hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch, sel,
-                           sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off);
+                           sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, pts_cap, (int)pts_off);
+    }
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }

@@ -30,7 +30,7 @@ void set_error(const char *fmt, ...)
 
 int launch_halo_full(hipStream_t st, int nimg, uint8_t *pyr, const Geom &G);
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
-                   const Geom &G, const XTab *xtab, const YTab *ytab);
+                   const Geom &G, const XTab *xtab, const YTab *ytab, const FuseArgs *fuse);
 int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
                 int32_t *cell_counts);
 int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
@@ -171,6 +171,8 @@ struct orbgpu_extractor {
     int graph_nimg = 0, graph_w = 0, graph_h = 0;
     bool graph_broken = false;  // capture failed once: plain launches from then on
     DevBuf pyr, blur, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, pattern, xtab, ytab, cell_tab, blur_tab;
+    DevBuf fuse_tab;
+    FuseArgs fuse = {nullptr, 0, 0};  // the single-launch pyramid of a few frames (k_pyr_fused), if the geometry allows it
     int blur_tiles = 0;
     // staging for the host entry points: images; and one block for keypoints | descriptors | counts | status word, so
     // that a small call brings everything back with one copy
@@ -470,6 +472,52 @@ static int set_geometry_unchecked(orbgpu_extractor *e, int w, int h)
     ORBGPU_HIP_CHECK(hipMemcpy(e->blur_tab.p, btab.data(), btab.size() * 4, hipMemcpyHostToDevice));
     ORBGPU_HIP_CHECK(hipMemcpy(e->xtab.p, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice));
     ORBGPU_HIP_CHECK(hipMemcpy(e->ytab.p, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice));
+    // Regions of the fused pyramid: a kFW x kFH tile of the last level, then level by level the taps of the region
+    // above (first tap of its first column / row .. second tap of its last), extended to the level's edge where the
+    // region above touches its own.  While every scale step is at most 2 each column (row) of a level is a tap of
+    // the next, so the regions of all tiles cover every level.  The region of level 0 is read from global memory in
+    // whole dwords (the rows have that much room behind the level).
+    e->fuse.tab = nullptr;
+    if (G.nlevels > 1) {
+        const LevelGeom &gl = G.lv[G.nlevels - 1];
+        const int tX = (gl.w + kFW - 1) / kFW, tY = (gl.h + kFH - 1) / kFH;
+        std::vector<FuseRegion> ftab((size_t)tX * tY * G.nlevels);
+        bool ok = true;
+        int64_t half = 0, entries = 0;
+        for (int l = 1; l < G.nlevels; l++)
+            if (G.lv[l - 1].w > 2 * G.lv[l].w || G.lv[l - 1].h > 2 * G.lv[l].h) ok = false;
+        for (int t = 0; t < tX * tY && ok; t++) {
+            const int tx = t % tX, ty = t / tX;
+            int x0 = tx * kFW, y0 = ty * kFH, x1 = std::min(tx * kFW + kFW, gl.w) - 1, y1 = std::min(ty * kFH + kFH, gl.h) - 1;
+            int64_t ne = 0;
+            for (int l = G.nlevels - 1; l >= 0; l--) {
+                if (l == 0) { x0 &= ~3; x1 |= 3; }
+                const FuseRegion r = {(int16_t)x0, (int16_t)y0, (int16_t)x1, (int16_t)y1};
+                ftab[(size_t)t * G.nlevels + l] = r;
+                const int64_t rw = x1 - x0 + 1, rh = y1 - y0 + 1;
+                if (l >= 1) ne += std::max(rw, rh);
+                if (l < G.nlevels - 1) half = std::max(half, rw * rh);
+                if (rw >= 500 || rw * rh >= 65536) ok = false;  // the kernel's index arithmetic
+                if (l == 0) break;
+                const LevelGeom &gd = G.lv[l], &gs = G.lv[l - 1];
+                const XTab *xl = &xt[gd.xtab_off];
+                const YTab *yl = &yt[gd.ytab_off];
+                const int nx0 = x0 == 0 ? 0 : xl[x0].sx, nx1 = x1 == gd.w - 1 ? gs.w - 1 : std::min(xl[x1].sx + 1, gs.w - 1);
+                const int ny0 = y0 == 0 ? 0 : yl[y0].sy0, ny1 = y1 == gd.h - 1 ? gs.h - 1 : std::min(yl[y1].sy1, gs.h - 1);
+                x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1;
+            }
+            entries = std::max(entries, ne);
+        }
+        half = (half + 15) & ~(int64_t)15;
+        entries = (entries + 1) & ~(int64_t)1;
+        if (ok && entries * 24 + 2 * half <= 60 * 1024) {
+            if ((rc = e->fuse_tab.ensure(ftab.size() * sizeof(FuseRegion) + 16))) return rc;
+            ORBGPU_HIP_CHECK(hipMemcpy(e->fuse_tab.p, ftab.data(), ftab.size() * sizeof(FuseRegion), hipMemcpyHostToDevice));
+            e->fuse.tab = (const FuseRegion *)e->fuse_tab.p;
+            e->fuse.lds_entries = (int)entries;
+            e->fuse.lds_half = (int)half;
+        }
+    }
     e->G = G;
     e->geom_w = w;
     e->geom_h = h;
@@ -557,7 +605,7 @@ void orbgpu_extractor_destroy(orbgpu_extractor *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drop_graph(e);
     DevBuf *bufs[] = {&e->pyr, &e->blur, &e->slots, &e->cell_counts, &e->cand, &e->nodes, &e->scratch, &e->sel, &e->sel_count,
-                      &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->cell_tab, &e->blur_tab, &e->st_img, &e->st_out};
+                      &e->cand_count, &e->status, &e->pattern, &e->xtab, &e->ytab, &e->cell_tab, &e->blur_tab, &e->fuse_tab, &e->st_img, &e->st_out};
     for (DevBuf *b : bufs) b->release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
@@ -731,26 +779,28 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     int32_t *status = e->status_cur;
     if (clear_status) ORBGPU_HIP_CHECK(hipMemsetAsync(status, 0, 4, st));
     STAGE_MARK(0);
-    if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, pyr, G, (const XTab *)e->xtab.p, (const YTab *)e->ytab.p)))
+    if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, pyr, G, (const XTab *)e->xtab.p, (const YTab *)e->ytab.p, &e->fuse)))
         return rc;
     STAGE_MARK(1);
     if ((rc = launch_fast(st, nimg, pyr, G, (const uint32_t *)e->cell_tab.p, slots, cell_counts))) return rc;
     STAGE_MARK(2);
     // fork: the blur depends on the pyramid only.  FAST keeps every SIMD busy, the
-    // quadtree is latency-bound, so the blur is released after FAST to run beside the quadtree
-    hipStream_t ax = e->serialize ? st : e->aux_stream;
-    if (!e->serialize) {
+    // quadtree is latency-bound, so the blur is released after FAST to run beside the quadtree.  For one or two
+    // frames the blur is a few microseconds and handing work to a second queue and back costs more than that.
+    const bool serial = e->serialize || nimg <= 2;
+    hipStream_t ax = serial ? st : e->aux_stream;
+    if (!serial) {
         ORBGPU_HIP_CHECK(hipEventRecord(e->ev_fork, st));
         ORBGPU_HIP_CHECK(hipStreamWaitEvent(ax, e->ev_fork, 0));
     }
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], ax));
     if ((rc = launch_blur(ax, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
-    if (!e->serialize) ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
+    if (!serial) ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
     if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status)))
         return rc;
     STAGE_MARK(3);
-    if (!e->serialize) ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
+    if (!serial) ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
     if ((rc = launch_describe(st, nimg, pyr, blur, G, sel, sel_count, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts, capacity,
                               status)))
         return rc;

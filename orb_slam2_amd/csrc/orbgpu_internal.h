@@ -16,6 +16,16 @@ constexpr int kScratchPerNode = 6;  // int32 words of quadtree scratch per entry
 constexpr int kMaxTile = 66;     // largest FAST cell incl. 3 px apron (cells are < 60 px)
 constexpr int kRW = 128, kRH = 32;  // output tile of one resize workgroup
 
+// Fused pyramid (k_pyr_fused): tile of the last level owned by a workgroup, and what the host tabulates for it: for
+// every tile and level the region {x0, y0, x1, y1} (inclusive) of the level that the tile depends on.
+constexpr int kFW = 16, kFH = 8;
+struct FuseRegion { int16_t x0, y0, x1, y1; };
+struct FuseArgs {
+    const FuseRegion *tab;  // [tile][nlevels], device memory; null: one launch per level
+    int lds_entries;        // column / row table entries a workgroup stages (sum over levels of max(region width, height))
+    int lds_half;           // bytes of the largest region a workgroup holds in LDS
+};
+
 // Horizontal / vertical coefficient tables of the fixed-point bilinear resize.
 struct XTab { int32_t sx; int16_t a0, a1; };
 struct YTab { int32_t sy0, sy1; int16_t b0, b1; int32_t pad; };
@@ -129,27 +139,32 @@ __device__ __forceinline__ bool frame_block(int nimg, int *f, int *b)
     return *f < nimg;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave (all lanes active) with data-parallel-primitive moves: shifts by
+// 1, 2, 4, 8 inside every row of 16 lanes, then lane 15 of a row added to the next row (rows 1 and 3) and lane 31 to
+// rows 2 and 3.  Six adds with a few wait states each; the same through lane permutes goes through the LDS crossbar
+// six times, about a hundred cycles apiece.
+__device__ __forceinline__ int wave_scan_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // Exclusive scan over the block (blockDim.x a multiple of 64, <= 1024).
 // lds needs 33 ints.  Every thread must call it.
 __device__ __forceinline__ int block_scan_excl(int v, int *total, int *lds)
 {
     const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
+    const int inc = wave_scan_incl(v);
     if (lane == 63) lds[wid] = inc;
     __syncthreads();
     if (wid == 0) {
-        int wv = lane < nw ? lds[lane] : 0;
-        int winc = wv;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            int t = __shfl_up(winc, o);
-            if (lane >= o) winc += t;
-        }
+        const int wv = lane < nw ? lds[lane] : 0;
+        const int winc = wave_scan_incl(wv);  // at most 16 waves: the first row's part of the scan
         if (lane < nw) lds[16 + lane] = winc - wv;
         if (lane == nw - 1) lds[32] = winc;
     }
