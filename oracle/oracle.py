@@ -181,7 +181,8 @@ class Extractor:
         self.p = make_params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, gauss_variant)
         self.h = lib().orc_extractor_create(C.byref(self.p))
         assert self.h
-        self.cap = nfeatures + 64 * nlevels
+        # a level can return up to 4 * max(quota, roots) nodes (strips much wider than high start from many roots)
+        self.cap = 4 * nfeatures + 600 * nlevels
 
     def __del__(self):
         if getattr(self, "h", None):

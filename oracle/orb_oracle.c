@@ -787,7 +787,10 @@ int orc_extract(orc_extractor *e, const uint8_t *img, int w, int h, int stride,
         const uint8_t *in = interior(e, l);
         int ccap = (e->lw[l] * e->lh[l]) / 4 + 1024;
         float *cx = (float *)malloc(sizeof(float) * 3 * (size_t)ccap);
-        int *sel = (int *)malloc(sizeof(int) * (size_t)(e->quota[l] + 64));
+        /* a subdivision round at most quadruples the node list, and it starts from up to 128 roots: the result of
+         * DistributeOctTree has fewer than 4 * max(N, roots) nodes */
+        const int scap = 4 * (e->quota[l] + 128) + 64;
+        int *sel = (int *)malloc(sizeof(int) * (size_t)scap);
         if (!cx || !sel) { free(cx); free(sel); rc = -2; break; }
         float *cy = cx + ccap, *cr = cy + ccap;
         int nc = orc_level_candidates(in, e->lw[l], e->lh[l], st, e->p.iniThFAST, e->p.minThFAST,
@@ -796,8 +799,8 @@ int orc_extract(orc_extractor *e, const uint8_t *img, int w, int h, int stride,
         int ts = 0;
         int ns = orc_distribute_octree(cx, cy, cr, nc, ORC_EDGE - 3, e->lw[l] - ORC_EDGE + 3,
                                        ORC_EDGE - 3, e->lh[l] - ORC_EDGE + 3, e->quota[l], sel,
-                                       e->quota[l] + 64, &ts);
-        if (ns < 0 || ns > e->quota[l] + 64) { free(cx); free(sel); rc = ns < 0 ? ns : -4; break; }
+                                       scap, &ts);
+        if (ns < 0 || ns > scap) { free(cx); free(sel); rc = ns < 0 ? ns : -4; break; }
         e->tie_straddles += ts;
         lvl_kps[l] = (orc_keypoint *)malloc(sizeof(orc_keypoint) * (size_t)(ns > 0 ? ns : 1));
         const int scaledPatch = (int)(31 * e->scale[l]); /* :1120 */

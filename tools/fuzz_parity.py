@@ -235,6 +235,82 @@ def compare_stereo(m, exL, exR, a, b, nlevels, rng):
     return None
 
 
+def compare_frame(m, ex, ex2, img, img2, a, b, w, h, nlevels, rng):
+    """The device-resident frame (orbgpu_frame_build_*) against the oracle: contents, grid, and one search with the
+    frame as the train side."""
+    (kA, dA), (kB, dB) = a, b
+    fx, fy = float(rng.uniform(200, 900)), float(rng.uniform(200, 900))
+    K4 = [fx, fy, w / 2 + float(rng.uniform(-20, 20)), h / 2 + float(rng.uniform(-20, 20))]
+    D5 = [0, 0, 0, 0, 0] if rng.random() < 0.4 else [float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2)),
+                                                     float(rng.uniform(-0.01, 0.01)), float(rng.uniform(-0.01, 0.01)),
+                                                     float(rng.uniform(-0.1, 0.1))]
+    if D5[0] == 0:
+        bounds = np.array([0, 0, w, h], np.float32)
+    else:
+        c = np.zeros(4, O.KEYPOINT_DTYPE)
+        c["x"] = [0, w, 0, w]; c["y"] = [0, 0, h, h]
+        u = O.undistort_keypoints(c, K4, D5)
+        bounds = np.array([min(u["x"][0], u["x"][2]), min(u["y"][0], u["y"][1]), max(u["x"][1], u["x"][3]), max(u["y"][2], u["y"][3])],
+                          np.float32)
+        if not (bounds[2] > bounds[0] + 8 and bounds[3] > bounds[1] + 8):
+            return None  # a distortion that folds the image: no frame to speak of
+    kind = int(rng.integers(3))
+    f = api.Frame(ex.max_keypoints)
+    bf = fx * float(rng.uniform(0.05, 0.6))
+    if kind == 0:
+        f.build_mono(ex, img, K4, D5, bounds)
+        rur = np.full(len(kA), -1, np.float32); rdp = rur.copy(); rnv = 0
+    elif kind == 1:
+        depth = rng.uniform(0.3, 8.0, (h, w)).astype(np.float32)
+        depth[rng.random(depth.shape) < 0.2] = 0.0
+        f.build_rgbd(ex, img, depth, bf, K4, D5, bounds)
+    else:
+        _, nv = f.build_stereo(ex, ex2, img, img2, bf, bf / fx, K4, D5, bounds)
+        pyrL = [ex.pyramid_level(l) for l in range(nlevels)]
+        pyrR = [ex2.pyramid_level(l) for l in range(nlevels)]
+        sc = np.asarray(ex.GetScaleFactors(), np.float32); isc = np.asarray(ex.GetInverseScaleFactors(), np.float32)
+        rnv, rur, rdp = O.stereo_matches(kA, dA, kB, dB, pyrL, pyrR, sc, isc, bf, bf / fx)
+    what = ("mono", "rgbd", "stereo")[kind]
+    if f.N != len(kA):
+        return "frame (%s): %d keypoints, the extraction %d" % (what, f.N, len(kA))
+    for fld in ("x", "y", "size", "response", "octave", "class_id"):
+        if not np.array_equal(f.mvKeys[fld], kA[fld]):
+            return "frame (%s): keypoint field %s differs from the extraction" % (what, fld)
+    # angles and descriptors: the bar of compare_extract (the oracle's float sin / cos may round differently)
+    if f.N and (np.abs(f.mvKeys["angle"] - kA["angle"]).max() > np.degrees(1e-4) or (f.mDescriptors != dA).any(axis=1).sum() > max(1, f.N // 1000)):
+        return "frame (%s): angles / descriptors differ from the extraction" % what
+    ru = O.undistort_keypoints(kA, K4, D5) if D5[0] != 0 else kA
+    un = f.mvKeysUn
+    if len(kA) and (np.abs(un["x"] - ru["x"]).max() > 1e-3 or np.abs(un["y"] - ru["y"]).max() > 1e-3 or not np.array_equal(un["octave"], kA["octave"])):
+        return "frame (%s): undistorted keypoints differ by %g px" % (what, float(np.abs(un["x"] - ru["x"]).max()))
+    if kind == 1:
+        rur, rdp = O.stereo_from_rgbd(kA, un.view(O.KEYPOINT_DTYPE), depth, bf)
+        rnv = int((rdp > 0).sum())
+    if not np.array_equal(f.mvuRight, rur) or not np.array_equal(f.mvDepth, rdp) or f.nvalid != rnv:
+        return "frame (%s): uRight / depth differ at %d keypoints (valid %d vs %d)" % (what, int((f.mvuRight != rur).sum()), f.nvalid, rnv)
+    cs, ci = f.grid()
+    rcs, rci = O.grid_build(un.view(O.KEYPOINT_DTYPE), bounds)
+    if not np.array_equal(cs, rcs) or not np.array_equal(ci, rci):
+        return "frame (%s): grid differs" % what
+    if len(kB) == 0 or f.N == 0:
+        return None
+    mode = int(rng.integers(0, 3))
+    th = float(rng.uniform(2, 40))
+    q = api.shift_queries(kB, float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)), th, np.asarray(ex.GetScaleFactors(), np.float32), bounds)
+    if mode == 0:
+        q["minLevel"] = kB["octave"] - 1
+        q["maxLevel"] = kB["octave"]
+    q["ur"] = q["u"] - float(rng.uniform(0, 30))
+    q = q.astype(api.WQUERY_DTYPE)
+    occ = (rng.random(f.N) < 0.1).astype(np.uint8)
+    n, assign = m.SearchByProjectionFrame(mode, q, dB, f, occupied=occ, th_dist=100)
+    rn, rassign = O.search_by_projection(mode, q.view(O.WQUERY_DTYPE), dB, un.view(O.KEYPOINT_DTYPE), dA, bounds, uright2=f.mvuRight,
+                                         occupied=occ, th_dist=100, nnratio=m.mfNNratio, checkOri=m.mbCheckOrientation)
+    if n != rn or not np.array_equal(assign, rassign):
+        return "frame (%s): SearchByProjection mode %d against the resident frame: %d vs %d" % (what, mode, n, rn)
+    return None
+
+
 def main(argv=None, stats_out=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
@@ -257,7 +333,9 @@ def main(argv=None, stats_out=None):
         nlevels = int(rng.integers(1, 11))
         w, h = int(rng.integers(70, 1300)), int(rng.integers(70, 1000))
         if rng.random() < 0.95:
-            h = min(h, 2 * w - 40)  # portrait frames whose search area is more than twice as tall as wide get no quadtree root
+            # portrait frames whose search area (side - 26 on every level) is more than twice as tall as wide get no
+            # quadtree root, in the reference (which then indexes an empty vector) as here: draw few of them
+            h = min(h, int(1.45 * w))
         # the smallest level must keep a search area: sides of at least 62 px
         while nlevels > 1 and min(w, h) / scale ** (nlevels - 1) < 64:
             nlevels -= 1
@@ -301,6 +379,8 @@ def main(argv=None, stats_out=None):
                 err = compare_match2(a, b, w, h, np.asarray(ex.GetScaleFactors(), np.float32), rng)
             if err is None and rng.random() < 0.3 and len(a[0]) <= 16384:
                 err = compare_bow(a, rng)
+            if err is None and rng.random() < 0.5:
+                err = compare_frame(m, ex, ex2, img, img2, a, b, w, h, nlevels, rng)
             nmatch += 1
         if err is not None:
             nfail += 1
