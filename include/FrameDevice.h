@@ -21,6 +21,7 @@
 #define ORBGPU_FRAME_DEVICE_H
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 

@@ -74,3 +74,13 @@ def test_shard_frames_partitions():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_frames(10, 2, 2)
+
+
+def test_opencv_branch_of_the_headers_type_checks():
+    """The ORBGPU_WITH_OPENCV branch of include/*.h (what a real ORB-SLAM2 build uses) and the eleven reference-signature
+    templates on types that hold cv::Mat like the reference's: compiled with -fsyntax-only against declarations that carry
+    OpenCV's signatures (tests/cpp/fake_opencv; OpenCV itself is absent from this image, so nothing is linked or run)."""
+    import subprocess
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-fsyntax-only",
+                           "-I" + os.path.join(ROOT, "tests", "cpp", "fake_opencv"), "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "opencv_branch_probe.cc")])
