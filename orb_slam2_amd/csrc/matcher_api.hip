@@ -96,6 +96,11 @@ struct orbgpu_matcher {
     MBuf stats;    // resolver statistics of the last window call
     int stats_pairs = 0;
     MBuf stage[12];  // staging for the host entry points
+    // the windowed / segmented searches move their host operands in one block each way: a device block and its
+    // page-locked twin, laid out per call (window_host)
+    MBuf io;
+    void *h_io = nullptr;
+    size_t h_io_bytes = 0;
     bool geom_set = false;  // one-shot grid geometry of the next windowed call (orbgpu_matcher_set_grid_geometry)
     float geom[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -199,6 +204,8 @@ void orbgpu_matcher_destroy(orbgpu_matcher *m)
     m->scratch.release();
     m->stats.release();
     for (auto &b : m->stage) b.release();
+    m->io.release();
+    if (m->h_io) (void)hipHostFree(m->h_io);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
 }
@@ -379,10 +386,17 @@ struct WindowDev {
     const orbgpu_frame *train = nullptr;   // the train side is this frame (keypoints, descriptors, uRight, grid)
     const orbgpu_wquery *d_q = nullptr;    // the queries and their descriptors (both or neither)
     const uint8_t *d_qdesc = nullptr;
+    // SearchForInitialization between two frames: the queries are made on the device from init_f1's undistorted
+    // keypoints and prev_xy (vbPrevMatched, in / out: it travels inside the block, updated on the device)
+    const orbgpu_frame *init_f1 = nullptr;
+    float *prev_xy = nullptr;
+    int window = 0;
 };
 
-// Front end shared by the windowed and segmented searches: host arrays are staged on the device, operands named in
-// `dev` are used where they lie.
+// Front end shared by the windowed and segmented searches.  Host arrays travel in ONE block each way (a call with a
+// thousand keypoints is a dozen small arrays: copied one by one, the copies cost more than the kernels): the inputs
+// are packed into the handle's page-locked block and uploaded with one copy, the outputs (assign | qmatch | counts)
+// come back with one.  Operands named in `dev` are used where they lie on the device.
 static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, const uint8_t *qdesc, int32_t nq,
                        const orbgpu_keypoint *kps2, const uint8_t *desc2, const float *uright2, int32_t n2, const float *b4,
                        const uint8_t *occupied, int32_t *assign, int32_t *qmatch, int32_t th_dist, float nnratio, int32_t ori,
@@ -392,59 +406,80 @@ static int window_host(orbgpu_matcher *m, int32_t mode, const orbgpu_wquery *q, 
     ORBGPU_HIP_CHECK(hipSetDevice(m->device));
     hipStream_t st = m->stream;
     const orbgpu_frame *train = dev ? dev->train : nullptr;
+    const orbgpu_frame *f1 = dev ? dev->init_f1 : nullptr;
     const bool dev_q = dev && dev->d_q;
     // a frame's grid is laid out for the frame's capacity
-    const int qc = nq > 0 ? nq : 1, tc = train ? train->capacity : (n2 > 0 ? n2 : 1);
-    int rc;
-    if (!dev_q) {
-        if ((rc = m->stage[0].ensure((size_t)qc * sizeof(orbgpu_wquery)))) return rc;
-        if ((rc = m->stage[1].ensure((size_t)qc * 32))) return rc;
-    }
-    if (!train) {
-        if ((rc = m->stage[2].ensure((size_t)tc * sizeof(orbgpu_keypoint)))) return rc;
-        if ((rc = m->stage[3].ensure((size_t)tc * 32))) return rc;
-        if ((rc = m->stage[4].ensure((size_t)tc * 4))) return rc;
-    }
-    if ((rc = m->stage[5].ensure((size_t)tc))) return rc;
-    if ((rc = m->stage[6].ensure((size_t)tc * 4))) return rc;
-    if ((rc = m->stage[7].ensure((size_t)qc * 4))) return rc;
-    if ((rc = m->stage[8].ensure(64))) return rc;
+    const size_t qc = nq > 0 ? nq : 1, tc = train ? train->capacity : (n2 > 0 ? n2 : 1);
     const int32_t nidx = seg_start ? seg_start[nseg] : 0;
-    if (seg_start) {
-        if ((rc = m->stage[9].ensure((size_t)(nseg + 1) * 4))) return rc;
-        if ((rc = m->stage[10].ensure((size_t)(nidx > 0 ? nidx : 1) * 4))) return rc;
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[9].p, seg_start, (size_t)(nseg + 1) * 4, hipMemcpyHostToDevice, st));
-        if (nidx > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[10].p, seg_index, (size_t)nidx * 4, hipMemcpyHostToDevice, st));
+    // block layout (offsets in bytes, every part 256-byte aligned): inputs first, outputs last
+    size_t off = 0;
+    auto part = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_cnt = part(16);
+    const size_t o_q = part(dev_q ? 0 : qc * sizeof(orbgpu_wquery)), o_qd = part(dev_q || f1 ? 0 : qc * 32);
+    const size_t o_k2 = part(train ? 0 : tc * sizeof(orbgpu_keypoint)), o_d2 = part(train ? 0 : tc * 32);
+    const size_t o_ur = part(train || !uright2 ? 0 : tc * 4), o_occ = part(occupied ? tc : 0);
+    const size_t o_ss = part(seg_start ? (size_t)(nseg + 1) * 4 : 0), o_si = part(seg_start ? (size_t)(nidx > 0 ? nidx : 1) * 4 : 0);
+    const size_t o_prev = part(f1 ? qc * 8 : 0);  // last input, first output
+    const size_t in_bytes = off;
+    const size_t o_as = part(tc * 4), o_qm = part(qc * 4), o_out = part(16);
+    const size_t total = off;
+    int rc;
+    if ((rc = m->io.ensure(total))) return rc;
+    if (total > m->h_io_bytes) {
+        if (m->h_io) (void)hipHostFree(m->h_io);
+        m->h_io = nullptr;
+        m->h_io_bytes = 0;
+        const size_t want = total + total / 4 + 4096;
+        if (hipHostMalloc(&m->h_io, want, hipHostMallocDefault) != hipSuccess) {
+            set_error("hipHostMalloc of %zu bytes failed", want);
+            return ORBGPU_E_NOMEM;
+        }
+        m->h_io_bytes = want;
     }
-    if (nq > 0 && !dev_q) {
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, q, (size_t)nq * sizeof(orbgpu_wquery), hipMemcpyHostToDevice, st));
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[1].p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    uint8_t *h = (uint8_t *)m->h_io, *d = (uint8_t *)m->io.p;
+    int32_t *hc = (int32_t *)(h + o_cnt);
+    hc[0] = nq; hc[1] = n2; hc[2] = 0; hc[3] = 0;
+    if (nq > 0 && f1) {
+        memcpy(h + o_prev, dev->prev_xy, (size_t)nq * 8);
+    } else if (nq > 0 && !dev_q) {
+        memcpy(h + o_q, q, (size_t)nq * sizeof(orbgpu_wquery));
+        memcpy(h + o_qd, qdesc, (size_t)nq * 32);
     }
     if (n2 > 0) {
         if (!train) {
-            ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[2].p, kps2, (size_t)n2 * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
-            ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[3].p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
-            if (uright2) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[4].p, uright2, (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+            memcpy(h + o_k2, kps2, (size_t)n2 * sizeof(orbgpu_keypoint));
+            memcpy(h + o_d2, desc2, (size_t)n2 * 32);
+            if (uright2) memcpy(h + o_ur, uright2, (size_t)n2 * 4);
         }
-        if (occupied) ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[5].p, occupied, (size_t)n2, hipMemcpyHostToDevice, st));
+        if (occupied) memcpy(h + o_occ, occupied, (size_t)n2);
     }
-    int32_t hc[4] = {nq, n2, 0, 0};
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[8].p, hc, 16, hipMemcpyHostToDevice, st));
-    int32_t *dc = (int32_t *)m->stage[8].p;
-    const orbgpu_keypoint *d_k2 = train ? train->kps_un : (const orbgpu_keypoint *)m->stage[2].p;
-    const uint8_t *d_d2 = train ? train->desc : (const uint8_t *)m->stage[3].p;
-    const float *d_ur = !uright2 ? nullptr : train ? train->uright : (const float *)m->stage[4].p;
-    rc = run_window(m, mode, 1, dev_q ? dev->d_q : (const orbgpu_wquery *)m->stage[0].p, dev_q ? dev->d_qdesc : (const uint8_t *)m->stage[1].p,
-                    dc, qc, d_k2, d_d2, d_ur, dc + 1, tc, b4, occupied ? (const uint8_t *)m->stage[5].p : nullptr,
-                    (int32_t *)m->stage[6].p, (int32_t *)m->stage[7].p, th_dist, nnratio, ori, dc + 2,
-                    seg_start ? (const int32_t *)m->stage[9].p : nullptr, seg_start ? (const int32_t *)m->stage[10].p : nullptr, extra,
+    if (seg_start) {
+        memcpy(h + o_ss, seg_start, (size_t)(nseg + 1) * 4);
+        if (nidx > 0) memcpy(h + o_si, seg_index, (size_t)nidx * 4);
+    }
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+    if (f1 && nq > 0 && (rc = launch_init_queries(st, f1->kps_un, nq, (const float *)(d + o_prev), dev->window, (orbgpu_wquery *)(d + o_q))))
+        return rc;
+    int32_t *dc = (int32_t *)(d + o_cnt);
+    const orbgpu_keypoint *d_k2 = train ? train->kps_un : (const orbgpu_keypoint *)(d + o_k2);
+    const uint8_t *d_d2 = train ? train->desc : d + o_d2;
+    const float *d_ur = !uright2 ? nullptr : train ? train->uright : (const float *)(d + o_ur);
+    rc = run_window(m, mode, 1, dev_q ? dev->d_q : (const orbgpu_wquery *)(d + o_q), dev_q ? dev->d_qdesc : f1 ? f1->desc : d + o_qd, dc,
+                    (int32_t)qc,
+                    d_k2, d_d2, d_ur, dc + 1, (int32_t)tc, b4, occupied ? d + o_occ : nullptr, (int32_t *)(d + o_as),
+                    (int32_t *)(d + o_qm), th_dist, nnratio, ori, (int32_t *)(d + o_out),
+                    seg_start ? (const int32_t *)(d + o_ss) : nullptr, seg_start ? (const int32_t *)(d + o_si) : nullptr, extra,
                     train ? train->grid() : nullptr);
     if (rc) return rc;
-    if (assign && n2 > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(assign, m->stage[6].p, (size_t)n2 * 4, hipMemcpyDeviceToHost, st));
-    if (qmatch && nq > 0) ORBGPU_HIP_CHECK(hipMemcpyAsync(qmatch, m->stage[7].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(hc, dc, 16, hipMemcpyDeviceToHost, st));
+    // :566-568 on the device: vbPrevMatched[i] = position of the matched keypoint of frame 2
+    if (f1 && nq > 0 && (rc = launch_init_update(st, (const int32_t *)(d + o_qm), nq, d_k2, (float *)(d + o_prev)))) return rc;
+    const size_t o_back = f1 ? o_prev : o_as;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(h + o_back, d + o_back, total - o_back, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
-    *nmatches = hc[2];
+    if (f1 && nq > 0) memcpy(dev->prev_xy, h + o_prev, (size_t)nq * 8);
+    if (assign && n2 > 0) memcpy(assign, h + o_as, (size_t)n2 * 4);
+    if (qmatch && nq > 0) memcpy(qmatch, h + o_qm, (size_t)nq * 4);
+    *nmatches = *(const int32_t *)(h + o_out);
     return ORBGPU_OK;
 }
 
@@ -964,30 +999,13 @@ int orbgpu_search_for_initialization_frames(orbgpu_matcher *m, const orbgpu_fram
     int rc = check_train_frame("orbgpu_search_for_initialization_frames", m, f1);
     if (rc) return rc;
     if ((rc = check_train_frame("orbgpu_search_for_initialization_frames", m, f2))) return rc;
-    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = m->stream;
-    const int n1 = f1->n;
-    if ((rc = m->stage[0].ensure((size_t)(n1 > 0 ? n1 : 1) * sizeof(orbgpu_wquery)))) return rc;
-    if ((rc = m->stage[11].ensure((size_t)(n1 > 0 ? n1 : 1) * 8))) return rc;
-    if (n1 > 0) {
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[11].p, prev_matched_xy, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
-        if ((rc = launch_init_queries(st, f1->kps_un, n1, (const float *)m->stage[11].p, window_size, (orbgpu_wquery *)m->stage[0].p)))
-            return rc;
-    }
     WindowDev dev;
     dev.train = f2;
-    dev.d_q = (const orbgpu_wquery *)m->stage[0].p;
-    dev.d_qdesc = f1->desc;
-    // window_host downloads matches12 and waits; the update of vbPrevMatched then reads the device copy of matches12
-    rc = window_host(m, 3, nullptr, nullptr, n1, nullptr, nullptr, nullptr, f2->n, f2->bounds4, nullptr, nullptr, matches12, ORBGPU_TH_LOW,
-                     nnratio, check_orientation, nmatches, nullptr, nullptr, 0, nullptr, &dev);
-    if (rc) return rc;
-    if (n1 > 0) {
-        if ((rc = launch_init_update(st, (const int32_t *)m->stage[7].p, n1, f2->kps_un, (float *)m->stage[11].p))) return rc;
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(prev_matched_xy, m->stage[11].p, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
-        ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
-    }
-    return ORBGPU_OK;
+    dev.init_f1 = f1;
+    dev.prev_xy = prev_matched_xy;
+    dev.window = window_size;
+    return window_host(m, 3, nullptr, nullptr, f1->n, nullptr, nullptr, nullptr, f2->n, f2->bounds4, nullptr, nullptr, matches12, ORBGPU_TH_LOW,
+                       nnratio, check_orientation, nmatches, nullptr, nullptr, 0, nullptr, &dev);
 }
 
 }  // extern "C"
