@@ -500,3 +500,27 @@ def test_many_roots_and_many_features_per_level(oracle):
     for f in ("x", "y", "size", "response", "octave"):
         assert np.array_equal(kps[f], okps[f]), f
     assert int((desc != odesc).any(axis=1).sum()) <= 0.001 * len(desc)
+
+
+def test_quadtree_tie_rule_is_locked(oracle):
+    """Among quadtree nodes of equal size the partial passes take the latest-created first (the reference orders them
+    by heap address, src/ORBextractor.cc:906).  On a frame where such ties straddle the cut the device must agree
+    with the oracle under that rule, and the comparison must notice the other order (earliest-created first)."""
+    from orb_slam2_amd.api import ORBextractor
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    oe = oracle.Extractor(1000)
+    seen = 0
+    for img in synth.sequence(640, 480, 4, seed=3):
+        kps, desc = ex(img)
+        okps, _ = oe.extract(img)
+        assert oe.tie_straddles() > 0  # these frames do have ties at the cut
+        assert kps.tobytes() == okps.tobytes()
+        oracle.set_tie_rule(1)
+        try:
+            akps, _ = oe.extract(img)
+        finally:
+            oracle.set_tie_rule(0)
+        mine = set(zip(kps["x"].tolist(), kps["y"].tolist(), kps["octave"].tolist()))
+        other = set(zip(akps["x"].tolist(), akps["y"].tolist(), akps["octave"].tolist()))
+        seen += len(mine - other)
+    assert seen > 0  # the other order selects different keypoints: the rule is what the equality above pins
