@@ -6,6 +6,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <string>
 #include <vector>
 
 #include "frame_internal.h"
@@ -66,29 +67,27 @@ __global__ __launch_bounds__(256) void k_frame_finish(const orbgpu_keypoint *__r
 }
 
 // Row table of ComputeStereoMatches (src/Frame.cc:610-627): right keypoint iR is listed in rows floor(y - r) ..
-// ceil(y + r), r = 2 * scale[octave]; every row lists its keypoints in ascending iR.  One workgroup: counts by LDS
-// atomics, a scan, then a thread per row walks the keypoints in order (their row spans staged in LDS by chunks).
-constexpr int kRowChunk = 4096;
-__global__ __launch_bounds__(1024) void k_stereo_rows(const orbgpu_keypoint *__restrict__ kpsR, const int32_t *__restrict__ d_nR, int capR,
-                                                      ScaleTab scale, int nlevels, int nRows, int32_t *__restrict__ row_start,
-                                                      int32_t *__restrict__ row_items)
+// ceil(y + r), r = 2 * scale[octave]; every row lists its keypoints in ascending iR.  Two launches: one workgroup
+// writes every keypoint's row span, counts the rows' entries with LDS atomics and scans them into the row starts;
+// then a wave per row walks the spans 64 at a time and appends the keypoints that cover its row at ballot ranks,
+// which keeps them in index order.
+__global__ __launch_bounds__(1024) void k_stereo_rows_count(const orbgpu_keypoint *__restrict__ kpsR, const int32_t *__restrict__ d_nR,
+                                                            int capR, ScaleTab scale, int nlevels, int nRows, int32_t *__restrict__ spans,
+                                                            int32_t *__restrict__ row_start)
 {
-    extern __shared__ int rows_lds[];  // nRows + 1 counts, then write cursors
+    extern __shared__ int rows_lds[];  // nRows + 1 counts
     __shared__ int scan_lds[33];
-    __shared__ short2 span[kRowChunk];
     const int tid = threadIdx.x;
     const int nR = min(max(*d_nR, 0), capR);
-    auto row_span = [&](int iR) {
-        const orbgpu_keypoint kp = kpsR[iR];
-        const float r = __fmul_rn(2.0f, scale.s[min(max(kp.octave, 0), nlevels - 1)]);
-        const int maxr = (int)ceilf(__fadd_rn(kp.y, r)), minr = (int)floorf(__fsub_rn(kp.y, r));
-        return make_int2(max(minr, 0), min(maxr, nRows - 1));
-    };
     for (int y = tid; y <= nRows; y += 1024) rows_lds[y] = 0;
     __syncthreads();
     for (int iR = tid; iR < nR; iR += 1024) {
-        const int2 s = row_span(iR);
-        for (int y = s.x; y <= s.y; y++) atomicAdd(&rows_lds[y], 1);
+        const orbgpu_keypoint kp = kpsR[iR];
+        const float r = __fmul_rn(2.0f, scale.s[min(max(kp.octave, 0), nlevels - 1)]);
+        const int maxr = (int)ceilf(__fadd_rn(kp.y, r)), minr = (int)floorf(__fsub_rn(kp.y, r));
+        const int lo = max(minr, 0), hi = min(maxr, nRows - 1);  // an empty span (above row 0 or past the last row) has lo > hi
+        spans[iR] = (lo & 0xFFFF) | (hi << 16);
+        for (int y = lo; y <= hi; y++) atomicAdd(&rows_lds[y], 1);
     }
     __syncthreads();
     int carry = 0;
@@ -97,30 +96,30 @@ __global__ __launch_bounds__(1024) void k_stereo_rows(const orbgpu_keypoint *__r
         const int v = y < nRows ? rows_lds[y] : 0;
         int total;
         const int ex = block_scan_excl(v, &total, scan_lds);
-        if (y < nRows) {
-            rows_lds[y] = carry + ex;
-            row_start[y] = carry + ex;
-        }
+        if (y < nRows) row_start[y] = carry + ex;
         carry += total;
     }
     if (tid == 0) row_start[nRows] = carry;
-    __syncthreads();
-    for (int c0 = 0; c0 < nR; c0 += kRowChunk) {
-        const int cn = min(kRowChunk, nR - c0);
-        for (int j = tid; j < cn; j += 1024) {
-            const int2 s = row_span(c0 + j);
-            span[j] = make_short2((short)s.x, (short)s.y);  // an empty span (below row 0 or past the last row) has x > y
+}
+
+__global__ __launch_bounds__(256) void k_stereo_rows_fill(const int32_t *__restrict__ spans, const int32_t *__restrict__ d_nR, int capR,
+                                                          int nRows, const int32_t *__restrict__ row_start, int32_t *__restrict__ row_items)
+{
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    if (y >= nRows) return;
+    const int nR = min(max(*d_nR, 0), capR);
+    int cur = row_start[y];
+    for (int base = 0; base < nR; base += 64) {
+        const int iR = base + lane;
+        bool covers = false;
+        if (iR < nR) {
+            const int s = spans[iR];
+            const int lo = s & 0xFFFF, hi = s >> 16;  // hi is negative for keypoints above the image
+            covers = lo <= y && y <= hi;
         }
-        __syncthreads();
-        for (int y = tid; y < nRows; y += 1024) {
-            int cur = rows_lds[y];
-            for (int j = 0; j < cn; j++) {
-                const short2 s = span[j];  // the same address for every lane: a broadcast
-                if (s.x <= y && y <= s.y) row_items[cur++] = c0 + j;
-            }
-            rows_lds[y] = cur;
-        }
-        __syncthreads();
+        const uint64_t m = __ballot(covers);
+        if (covers) row_items[cur + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = iR;
+        cur += __popcll(m);
     }
 }
 
@@ -330,6 +329,7 @@ void orbgpu_frame_destroy(orbgpu_frame *f)
     if (!f) return;
     (void)hipSetDevice(f->device);
     (void)hipDeviceSynchronize();  // matcher calls that read the frame may still be in flight
+    f->worker.stop();
     if (f->ev) (void)hipEventDestroy(f->ev);
     if (f->stereo_block) (void)hipFree(f->stereo_block);
     if (f->block) (void)hipFree(f->block);
@@ -400,8 +400,21 @@ int orbgpu_frame_build_stereo(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_ex
     // the two extractions run side by side on the two handles' streams (two threads in the reference, :78-81)
     HostExtraction XL, XR;
     const uint8_t *oneL[1] = {imgL}, *oneR[1] = {imgR};
-    if ((rc = extract_host_begin(left, oneL, 1, w, h, stride, &XL))) return rc;
-    if ((rc = extract_host_begin(right, oneR, 1, w, h, stride, &XR))) return rc;
+    // the right image is staged and enqueued by the handle's helper thread while this one does the left image
+    int rcR = ORBGPU_OK;
+    std::string errR;
+    f->worker.start();
+    f->worker.submit([&] {
+        rcR = extract_host_begin(right, oneR, 1, w, h, stride, &XR);
+        if (rcR) errR = orbgpu_last_error();
+    });
+    rc = extract_host_begin(left, oneL, 1, w, h, stride, &XL);
+    f->worker.wait();
+    if (rc) return rc;
+    if (rcR) {
+        set_error("right image: %s", errR.c_str());
+        return rcR;
+    }
     hipStream_t st = XL.stream;
     if (XR.stream != st) {
         ORBGPU_HIP_CHECK(hipEventRecord(f->ev, XR.stream));
@@ -413,18 +426,20 @@ int orbgpu_frame_build_stereo(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_ex
         if ((rc = orbgpu_pyramid_level_device(right, 0, l, 0, &S.pyrR[l], &p2, &w2, &h2))) return rc;
         S.pitchR[l] = p2;
     }
-    // stereo working set: best SAD [capacity] | row_start [rows + 1] | row_items; a right keypoint spans at most
+    // stereo working set: best SAD [capacity] | row spans [right capacity] | row_start [rows + 1] | row_items; a right keypoint spans at most
     // 2 r + 3 rows, r = 2 * its level's scale
     const int nRows = h;
     const size_t span = (size_t)ceilf(4.0f * S.scale[S.nlevels - 1]) + 3;
     const size_t items = (size_t)XR.cap * (span < (size_t)nRows ? span : (size_t)nRows);
-    if ((rc = frame_stereo_block(f, ((size_t)f->capacity + (size_t)nRows + 1 + items) * 4))) return rc;
-    int32_t *best_sad = (int32_t *)f->stereo_block, *row_start = best_sad + f->capacity, *row_items = row_start + nRows + 1;
+    if ((rc = frame_stereo_block(f, ((size_t)f->capacity + (size_t)XR.cap + (size_t)nRows + 1 + items) * 4))) return rc;
+    int32_t *best_sad = (int32_t *)f->stereo_block, *spans = best_sad + f->capacity, *row_start = spans + XR.cap,
+            *row_items = row_start + nRows + 1;
     if ((rc = frame_finish_enqueue(f, XL, K4, dist5, 2, nullptr, w, h, bf))) return rc;
     ScaleTab sc;
     for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) sc.s[l] = S.scale[l < S.nlevels ? l : S.nlevels - 1];
-    hipLaunchKernelGGL(k_stereo_rows, dim3(1), dim3(1024), ((size_t)nRows + 1) * 4, st, XR.d_kps, XR.d_counts, XR.cap, sc, S.nlevels, nRows,
-                       row_start, row_items);
+    hipLaunchKernelGGL(k_stereo_rows_count, dim3(1), dim3(1024), ((size_t)nRows + 1) * 4, st, XR.d_kps, XR.d_counts, XR.cap, sc, S.nlevels,
+                       nRows, spans, row_start);
+    hipLaunchKernelGGL(k_stereo_rows_fill, dim3((nRows + 3) / 4), dim3(256), 0, st, spans, XR.d_counts, XR.cap, nRows, row_start, row_items);
     ORBGPU_HIP_CHECK(hipGetLastError());
     S.kpsL = f->kps; S.descL = f->desc; S.nL = f->capacity; S.d_nL = f->count;
     S.kpsR = XR.d_kps; S.descR = XR.d_desc; S.nR = XR.cap;

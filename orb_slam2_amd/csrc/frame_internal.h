@@ -1,9 +1,66 @@
 // The device-resident frame handle, shared by frame_api.hip (which builds it) and matcher_api.hip (whose *_frame
 // entry points read it).
 #pragma once
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "match_internal.h"
+
+// One helper thread of a frame handle: the stereo build enqueues the right image's extraction on it while the calling
+// thread enqueues the left one (staging copy + graph launch cost the host about 70 us per image; the reference runs
+// the two extractions on two threads as well, src/Frame.cc:78-81).  Started by the first stereo build.
+struct FrameWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = false, quit = false;
+    void start()
+    {
+        if (th.joinable()) return;
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [this] { return has_job || quit; });
+                if (quit) return;
+                std::function<void()> j = std::move(job);
+                has_job = false;
+                lk.unlock();
+                j();
+                lk.lock();
+                done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<void()> j)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(j);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return done; });
+    }
+    void stop()
+    {
+        if (!th.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            cv.notify_all();
+        }
+        th.join();
+    }
+};
 
 struct orbgpu_frame {
     int device = 0;
@@ -34,4 +91,5 @@ struct orbgpu_frame {
     std::vector<orbgpu_keypoint> h_kps;
     std::vector<uint8_t> h_desc;
     bool h_valid = false, distorted = false;
+    FrameWorker worker;
 };

@@ -39,8 +39,16 @@ def stereo(name, w, h, nfeat, bf, fx, seed):
         res["n"] = m.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, bf, bf / fx)[0]
         res["kp"] = (len(kL), len(kR))
     dt = timed(frame, 20)
-    print(json.dumps({"config": name, "ms_per_stereo_frame_host_api_incl_pcie": dt * 1e3, "keypoints": res["kp"],
-                      "stereo_matches": res["n"]}), flush=True)
+    # the same frame through the device-resident frame handle: both extractions side by side, row table, matching,
+    # refinement and outlier cut on the device, one wait (Frame::Frame stereo, src/Frame.cc:58-116)
+    fr = api.Frame(exL.max_keypoints)
+    K4, b4 = [fx, fx, w / 2, h / 2], [0, 0, w, h]
+
+    def frame2():
+        res["n2"] = fr.build_stereo(exL, exR, L, R, bf, bf / fx, K4, [0, 0, 0, 0, 0], b4)[1]
+    dt2 = timed(frame2, 20)
+    print(json.dumps({"config": name, "ms_per_stereo_frame_host_api_incl_pcie": dt * 1e3, "ms_per_stereo_frame_frame_handle": dt2 * 1e3,
+                      "keypoints": res["kp"], "stereo_matches": res["n"], "stereo_matches_frame_handle": res["n2"]}), flush=True)
 
 
 def batch_4k(B=16):
