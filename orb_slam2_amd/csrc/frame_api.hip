@@ -15,6 +15,10 @@
 namespace orbgpu {
 int launch_grid_only(hipStream_t st, const MatchArgs &A);
 int launch_stereo(hipStream_t st, const StereoArgs &A);
+int launch_stereo_rows(hipStream_t st, const orbgpu_keypoint *kpsR, const int32_t *d_nR, int capR, const ScaleTab &scale, int nlevels, int nRows,
+                       int32_t *spans, int32_t *row_start, int32_t *row_items);
+int launch_stereo_outliers(hipStream_t st, const int32_t *best_sad, const int32_t *d_nL, int capL, float *uRight, float *depth,
+                           int32_t *nvalid);
 
 struct FrameOut {
     orbgpu_keypoint *kps, *kps_un;
@@ -64,126 +68,6 @@ __global__ __launch_bounds__(256) void k_frame_finish(const orbgpu_keypoint *__r
             F.uright[i] = -1.0f;
         }
     }
-}
-
-// Row table of ComputeStereoMatches (src/Frame.cc:610-627): right keypoint iR is listed in rows floor(y - r) ..
-// ceil(y + r), r = 2 * scale[octave]; every row lists its keypoints in ascending iR.  Two launches: one workgroup
-// writes every keypoint's row span, counts the rows' entries with LDS atomics and scans them into the row starts;
-// then a wave per row walks the spans 64 at a time and appends the keypoints that cover its row at ballot ranks,
-// which keeps them in index order.
-__global__ __launch_bounds__(1024) void k_stereo_rows_count(const orbgpu_keypoint *__restrict__ kpsR, const int32_t *__restrict__ d_nR,
-                                                            int capR, ScaleTab scale, int nlevels, int nRows, int32_t *__restrict__ spans,
-                                                            int32_t *__restrict__ row_start)
-{
-    extern __shared__ int rows_lds[];  // nRows + 1 counts
-    __shared__ int scan_lds[33];
-    const int tid = threadIdx.x;
-    const int nR = min(max(*d_nR, 0), capR);
-    for (int y = tid; y <= nRows; y += 1024) rows_lds[y] = 0;
-    __syncthreads();
-    for (int iR = tid; iR < nR; iR += 1024) {
-        const orbgpu_keypoint kp = kpsR[iR];
-        const float r = __fmul_rn(2.0f, scale.s[min(max(kp.octave, 0), nlevels - 1)]);
-        const int maxr = (int)ceilf(__fadd_rn(kp.y, r)), minr = (int)floorf(__fsub_rn(kp.y, r));
-        const int lo = max(minr, 0), hi = min(maxr, nRows - 1);  // an empty span (above row 0 or past the last row) has lo > hi
-        spans[iR] = (lo & 0xFFFF) | (hi << 16);
-        for (int y = lo; y <= hi; y++) atomicAdd(&rows_lds[y], 1);
-    }
-    __syncthreads();
-    int carry = 0;
-    for (int b = 0; b < nRows; b += 1024) {
-        const int y = b + tid;
-        const int v = y < nRows ? rows_lds[y] : 0;
-        int total;
-        const int ex = block_scan_excl(v, &total, scan_lds);
-        if (y < nRows) row_start[y] = carry + ex;
-        carry += total;
-    }
-    if (tid == 0) row_start[nRows] = carry;
-}
-
-__global__ __launch_bounds__(256) void k_stereo_rows_fill(const int32_t *__restrict__ spans, const int32_t *__restrict__ d_nR, int capR,
-                                                          int nRows, const int32_t *__restrict__ row_start, int32_t *__restrict__ row_items)
-{
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
-    if (y >= nRows) return;
-    const int nR = min(max(*d_nR, 0), capR);
-    int cur = row_start[y];
-    for (int base = 0; base < nR; base += 64) {
-        const int iR = base + lane;
-        bool covers = false;
-        if (iR < nR) {
-            const int s = spans[iR];
-            const int lo = s & 0xFFFF, hi = s >> 16;  // hi is negative for keypoints above the image
-            covers = lo <= y && y <= hi;
-        }
-        const uint64_t m = __ballot(covers);
-        if (covers) row_items[cur + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = iR;
-        cur += __popcll(m);
-    }
-}
-
-// Outlier rejection of ComputeStereoMatches (src/Frame.cc:760-773): the median of the matched SADs is element
-// size / 2 of their ascending order; matches with SAD >= 1.5 * 1.4 * median lose their measurement.  The SAD of an
-// 11 x 11 window of bytes is below 2^15: the median comes out of a histogram of the high eight bits and one of the
-// low seven bits inside the bucket that holds it.
-__global__ __launch_bounds__(1024) void k_stereo_outliers(const int32_t *__restrict__ best_sad, const int32_t *__restrict__ d_nL, int capL,
-                                                          float *__restrict__ uRight, float *__restrict__ depth, int32_t *__restrict__ nvalid_out)
-{
-    __shared__ int hist[256];
-    __shared__ int removed;
-    const int tid = threadIdx.x;
-    const int n = min(max(*d_nL, 0), capL);
-    if (tid < 256) hist[tid] = 0;
-    if (tid == 0) removed = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const int s = best_sad[i];
-        if (s >= 0) atomicAdd(&hist[min(s >> 7, 255)], 1);
-    }
-    __syncthreads();
-    // every thread walks the histogram itself (broadcast reads): the number of matches, the bucket of the median and
-    // the matches below that bucket
-    int total = 0;
-    for (int k = 0; k < 256; k++) total += hist[k];
-    if (total == 0) {
-        if (tid == 0) *nvalid_out = 0;
-        return;
-    }
-    const int kmed = total / 2;
-    int b = 0, acc = 0;
-    for (; b < 255; b++) {
-        if (kmed < acc + hist[b]) break;
-        acc += hist[b];
-    }
-    __syncthreads();
-    if (tid < 128) hist[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const int s = best_sad[i];
-        if (s >= 0 && min(s >> 7, 255) == b) atomicAdd(&hist[s & 127], 1);
-    }
-    __syncthreads();
-    int lo = 0;
-    for (; lo < 127; lo++) {
-        if (kmed < acc + hist[lo]) break;
-        acc += hist[lo];
-    }
-    const int bucket = (b << 7) | lo;
-    const float median = (float)bucket;
-    const float thDist = __fmul_rn(1.5f * 1.4f, median);
-    int mine = 0;
-    for (int i = tid; i < n; i += 1024) {
-        const int s = best_sad[i];
-        if (s >= 0 && !((float)s < thDist)) {
-            uRight[i] = -1.0f;
-            depth[i] = -1.0f;
-            mine++;
-        }
-    }
-    if (mine) atomicAdd(&removed, mine);
-    __syncthreads();
-    if (tid == 0) *nvalid_out = total - removed;
 }
 
 }  // namespace orbgpu
@@ -437,18 +321,14 @@ int orbgpu_frame_build_stereo(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_ex
     if ((rc = frame_finish_enqueue(f, XL, K4, dist5, 2, nullptr, w, h, bf))) return rc;
     ScaleTab sc;
     for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) sc.s[l] = S.scale[l < S.nlevels ? l : S.nlevels - 1];
-    hipLaunchKernelGGL(k_stereo_rows_count, dim3(1), dim3(1024), ((size_t)nRows + 1) * 4, st, XR.d_kps, XR.d_counts, XR.cap, sc, S.nlevels,
-                       nRows, spans, row_start);
-    hipLaunchKernelGGL(k_stereo_rows_fill, dim3((nRows + 3) / 4), dim3(256), 0, st, spans, XR.d_counts, XR.cap, nRows, row_start, row_items);
-    ORBGPU_HIP_CHECK(hipGetLastError());
+    if ((rc = launch_stereo_rows(st, XR.d_kps, XR.d_counts, XR.cap, sc, S.nlevels, nRows, spans, row_start, row_items))) return rc;
     S.kpsL = f->kps; S.descL = f->desc; S.nL = f->capacity; S.d_nL = f->count;
     S.kpsR = XR.d_kps; S.descR = XR.d_desc; S.nR = XR.cap;
     S.row_start = row_start; S.row_items = row_items; S.nRows = nRows;
     S.bf = bf; S.b = b;
     S.uRight = f->uright; S.depth = f->depth; S.best_sad = best_sad;
     if ((rc = launch_stereo(st, S))) return rc;
-    hipLaunchKernelGGL(k_stereo_outliers, dim3(1), dim3(1024), 0, st, best_sad, f->count, f->capacity, f->uright, f->depth, f->count + 1);
-    ORBGPU_HIP_CHECK(hipGetLastError());
+    if ((rc = launch_stereo_outliers(st, best_sad, f->count, f->capacity, f->uright, f->depth, f->count + 1))) return rc;
     if ((rc = frame_grid_enqueue(f, st))) return rc;
     if ((rc = frame_complete(f, XL, &XR, true, n_out))) return rc;
     if (nvalid_out) *nvalid_out = f->nvalid;

@@ -19,6 +19,10 @@ int launch_grid_only(hipStream_t st, const MatchArgs &A);
 int launch_shift_queries(hipStream_t st, int npairs, const orbgpu_keypoint *kps, const int32_t *n, int capacity, float du,
                          float dv, float th, const ScaleTab &sc, const float *b4, orbgpu_wquery *q);
 int launch_stereo(hipStream_t st, const StereoArgs &A);
+int launch_stereo_rows(hipStream_t st, const orbgpu_keypoint *kpsR, const int32_t *d_nR, int capR, const ScaleTab &scale, int nlevels, int nRows,
+                       int32_t *spans, int32_t *row_start, int32_t *row_items);
+int launch_stereo_outliers(hipStream_t st, const int32_t *best_sad, const int32_t *d_nL, int capL, float *uRight, float *depth,
+                           int32_t *nvalid);
 int launch_init_queries(hipStream_t st, const orbgpu_keypoint *kps1, int n1, const float *prev_xy, int window, orbgpu_wquery *q);
 int launch_init_update(hipStream_t st, const int32_t *matches12, int n1, const orbgpu_keypoint *kps2, float *prev_xy);
 int launch_distinctive(hipStream_t st, const uint8_t *d_desc, const int32_t *d_start, int npoints, int32_t *d_best_idx,
@@ -818,73 +822,66 @@ int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extrac
     // the extractors may run on other streams: make their work visible first
     if ((rc = orbgpu_extractor_sync(left))) return rc;
     if ((rc = orbgpu_extractor_sync(right))) return rc;
-    const int rc_ = nR > 0 ? nR : 1;
-    if ((rc = m->stage[0].ensure((size_t)nL * sizeof(orbgpu_keypoint)))) return rc;
-    if ((rc = m->stage[1].ensure((size_t)nL * 32))) return rc;
-    if ((rc = m->stage[2].ensure((size_t)rc_ * sizeof(orbgpu_keypoint)))) return rc;
-    if ((rc = m->stage[3].ensure((size_t)rc_ * 32))) return rc;
-    if ((rc = m->stage[4].ensure((size_t)nL * 4 * 3))) return rc;  // uRight, depth, best SAD
+    if (A.h[0] > 8192) {
+        set_error("orbgpu_stereo_match: images of more than 8192 rows are not supported");
+        return ORBGPU_E_UNSUPPORTED;
+    }
+    // One block each way, like the windowed searches: counts | left keypoints | left descriptors | right keypoints |
+    // right descriptors go up; uRight | depth | matches with a depth come back.  Between them, on the device: the
+    // row table (:610-627), the matching with its sub-pixel refinement, and the outlier cut on the SADs (:760-773).
     const int nRows = A.h[0];
-    if ((rc = m->stage[5].ensure(((size_t)nRows + 1) * 4 * 2))) return rc;  // row_start, cursor
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[0].p, kpsL, (size_t)nL * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[1].p, descL, (size_t)nL * 32, hipMemcpyHostToDevice, st));
+    const size_t capR = nR > 0 ? nR : 1;
+    const size_t span = (size_t)ceilf(4.0f * A.scale[nlev - 1]) + 3;  // a right keypoint lies in at most 2 r + 3 rows, r = 2 * scale
+    const size_t items = capR * (span < (size_t)nRows ? span : (size_t)nRows);
+    size_t off = 0;
+    auto part = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_cnt = part(16), o_kL = part((size_t)nL * sizeof(orbgpu_keypoint)), o_dL = part((size_t)nL * 32);
+    const size_t o_kR = part(capR * sizeof(orbgpu_keypoint)), o_dR = part(capR * 32);
+    const size_t in_bytes = off;
+    const size_t o_sp = part(capR * 4), o_rs = part(((size_t)nRows + 1) * 4), o_ri = part(items * 4), o_sad = part((size_t)nL * 4);
+    const size_t o_ur = part((size_t)nL * 4), o_dp = part((size_t)nL * 4), o_nv = part(16);
+    const size_t total = off, pinned = in_bytes + (total - o_ur);
+    if ((rc = m->io.ensure(total))) return rc;
+    if (pinned > m->h_io_bytes) {
+        if (m->h_io) (void)hipHostFree(m->h_io);
+        m->h_io = nullptr;
+        m->h_io_bytes = 0;
+        const size_t want = pinned + pinned / 4 + 4096;
+        if (hipHostMalloc(&m->h_io, want, hipHostMallocDefault) != hipSuccess) {
+            set_error("hipHostMalloc of %zu bytes failed", want);
+            return ORBGPU_E_NOMEM;
+        }
+        m->h_io_bytes = want;
+    }
+    uint8_t *h = (uint8_t *)m->h_io, *d = (uint8_t *)m->io.p;
+    int32_t *hc = (int32_t *)(h + o_cnt);
+    hc[0] = nL; hc[1] = nR; hc[2] = 0; hc[3] = 0;
+    memcpy(h + o_kL, kpsL, (size_t)nL * sizeof(orbgpu_keypoint));
+    memcpy(h + o_dL, descL, (size_t)nL * 32);
     if (nR > 0) {
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[2].p, kpsR, (size_t)nR * sizeof(orbgpu_keypoint), hipMemcpyHostToDevice, st));
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[3].p, descR, (size_t)nR * 32, hipMemcpyHostToDevice, st));
+        memcpy(h + o_kR, kpsR, (size_t)nR * sizeof(orbgpu_keypoint));
+        memcpy(h + o_dR, descR, (size_t)nR * 32);
     }
-    // Row table (src/Frame.cc:610-627): right keypoint iR is listed in rows
-    // floor(y-r)..ceil(y+r), r = 2*scale[octave]; lists keep ascending iR.
-    std::vector<int32_t> row_start((size_t)nRows + 1, 0);
-    for (int iR = 0; iR < nR; iR++) {
-        const float r = 2.0f * A.scale[kpsR[iR].octave];
-        const int maxr = (int)ceilf(kpsR[iR].y + r), minr = (int)floorf(kpsR[iR].y - r);
-        for (int y = minr; y <= maxr; y++)
-            if (y >= 0 && y < nRows) row_start[(size_t)y + 1]++;
-    }
-    for (int y = 0; y < nRows; y++) row_start[(size_t)y + 1] += row_start[y];
-    std::vector<int32_t> row_items((size_t)(row_start[nRows] > 0 ? row_start[nRows] : 1));
-    {
-        std::vector<int32_t> cur(row_start.begin(), row_start.end() - 1);
-        for (int iR = 0; iR < nR; iR++) {
-            const float r = 2.0f * A.scale[kpsR[iR].octave];
-            const int maxr = (int)ceilf(kpsR[iR].y + r), minr = (int)floorf(kpsR[iR].y - r);
-            for (int y = minr; y <= maxr; y++)
-                if (y >= 0 && y < nRows) row_items[cur[y]++] = iR;
-        }
-    }
-    if ((rc = m->stage[6].ensure(row_items.size() * 4))) return rc;
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[5].p, row_start.data(), row_start.size() * 4, hipMemcpyHostToDevice, st));
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(m->stage[6].p, row_items.data(), row_items.size() * 4, hipMemcpyHostToDevice, st));
-    A.kpsL = (const orbgpu_keypoint *)m->stage[0].p; A.descL = (const uint8_t *)m->stage[1].p; A.nL = nL;
-    A.kpsR = (const orbgpu_keypoint *)m->stage[2].p; A.descR = (const uint8_t *)m->stage[3].p; A.nR = nR;
-    A.row_start = (const int32_t *)m->stage[5].p; A.row_items = (const int32_t *)m->stage[6].p; A.nRows = nRows;
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+    const int32_t *dc = (const int32_t *)(d + o_cnt);
+    ScaleTab sc;
+    for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) sc.s[l] = A.scale[l < nlev ? l : nlev - 1];
+    if ((rc = launch_stereo_rows(st, (const orbgpu_keypoint *)(d + o_kR), dc + 1, (int)capR, sc, nlev, nRows, (int32_t *)(d + o_sp),
+                                 (int32_t *)(d + o_rs), (int32_t *)(d + o_ri))))
+        return rc;
+    A.kpsL = (const orbgpu_keypoint *)(d + o_kL); A.descL = d + o_dL; A.nL = nL;
+    A.kpsR = (const orbgpu_keypoint *)(d + o_kR); A.descR = d + o_dR; A.nR = nR;
+    A.row_start = (const int32_t *)(d + o_rs); A.row_items = (const int32_t *)(d + o_ri); A.nRows = nRows;
     A.bf = bf; A.b = b;
-    A.uRight = (float *)m->stage[4].p; A.depth = A.uRight + nL; A.best_sad = (int32_t *)(A.depth + nL);
+    A.uRight = (float *)(d + o_ur); A.depth = (float *)(d + o_dp); A.best_sad = (int32_t *)(d + o_sad);
     if ((rc = launch_stereo(st, A))) return rc;
-    std::vector<int32_t> sad((size_t)nL);
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(uRight, A.uRight, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(depth, A.depth, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
-    ORBGPU_HIP_CHECK(hipMemcpyAsync(sad.data(), A.best_sad, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+    if ((rc = launch_stereo_outliers(st, A.best_sad, dc, nL, A.uRight, A.depth, (int32_t *)(d + o_nv)))) return rc;
+    uint8_t *hb = h + in_bytes;  // the outputs' place in the page-locked block
+    ORBGPU_HIP_CHECK(hipMemcpyAsync(hb, d + o_ur, total - o_ur, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
-    // Outlier rejection on the SAD distribution (src/Frame.cc:760-773): sort
-    // (SAD, iL), threshold 1.5*1.4*median.  O(N log N) on <= N entries of host
-    // data; not part of the data-parallel work.
-    std::vector<std::pair<int, int>> v;
-    for (int i = 0; i < nL; i++)
-        if (sad[i] >= 0) v.push_back(std::make_pair(sad[i], i));
-    int valid = (int)v.size();
-    if (!v.empty()) {
-        std::sort(v.begin(), v.end());
-        const float median = (float)v[v.size() / 2].first;
-        const float thDist = 1.5f * 1.4f * median;
-        for (int i = (int)v.size() - 1; i >= 0; i--) {
-            if ((float)v[i].first < thDist) break;
-            uRight[v[i].second] = -1;
-            depth[v[i].second] = -1;
-            valid--;
-        }
-    }
-    *nvalid = valid;
+    memcpy(uRight, hb, (size_t)nL * 4);
+    memcpy(depth, hb + (o_dp - o_ur), (size_t)nL * 4);
+    *nvalid = *(const int32_t *)(hb + (o_nv - o_ur));
     return ORBGPU_OK;
 }
 
