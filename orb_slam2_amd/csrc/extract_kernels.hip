@@ -169,8 +169,10 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
             hB0 = (R[xo0] * a00 + R[xr0] * a01) >> 4;
             hB1 = (R[xo1] * a10 + R[xr1] * a11) >> 4;
         }
-        const int p0 = (((yv.b0 * hA0) >> 16) + ((yv.b1 * hB0) >> 16) + 2) >> 2;
-        const int p1 = (((yv.b0 * hA1) >> 16) + ((yv.b1 * hB1) >> 16) + 2) >> 2;
+        // (b * h) >> 16 as the high word of (b << 16) * h: the weights are 0 .. 2048 and uniform over the wave
+        const uint32_t B0 = (uint32_t)yv.b0 << 16, B1 = (uint32_t)yv.b1 << 16;
+        const int p0 = (int)(__umulhi(B0, (uint32_t)hA0) + __umulhi(B1, (uint32_t)hB0) + 2u) >> 2;
+        const int p1 = (int)(__umulhi(B0, (uint32_t)hA1) + __umulhi(B1, (uint32_t)hB1) + 2u) >> 2;
         // the row and, for rows next to the top / bottom edge, its reflect-101 image in the halo (tabulated)
         const int ym = (yv.pad & 0xFFFF) - 32;
         uint8_t *q = D + y * gd.pitch, *qm = D + ym * gd.pitch;  // 32-bit scalar row offsets (a frame's pyramid is < 2 GiB)
@@ -303,10 +305,10 @@ __global__ __launch_bounds__(1024) void k_pyr_fused(uint8_t *__restrict__ pyr, G
             const uint4 cy = ye[e0 + ry];
             const int c0 = (int)(cx.x & 0xFFFF), c1 = (int)(cx.x >> 16);
             const int a0 = (int16_t)(cx.y & 0xFFFF), a1 = (int16_t)(cx.y >> 16);
-            const int b0 = (int16_t)(cy.y & 0xFFFF), b1 = (int16_t)(cy.y >> 16);
             const uint8_t *A = S + (int)(cy.x & 0xFFFF) * sp, *B = S + (int)(cy.x >> 16) * sp;
             const int hA = (A[c0] * a0 + A[c1] * a1) >> 4, hB = (B[c0] * a0 + B[c1] * a1) >> 4;
-            const uint8_t p = (uint8_t)((((b0 * hA) >> 16) + ((b1 * hB) >> 16) + 2) >> 2);
+            // (b * h) >> 16 as the high word of (b << 16) * h (weights 0 .. 2048): b0 << 16 and b1 << 16 are the halves of cy.y
+            const uint8_t p = (uint8_t)((__umulhi(cy.y << 16, (uint32_t)hA) + __umulhi(cy.y & 0xFFFF0000u, (uint32_t)hB) + 2u) >> 2);
             if (l < l_last) Dl[i] = p;
             const int y = (int)cy.w, ym = (int)cy.z;  // the row and its reflect-101 image in the halo rows, if it has one
             Dg[y * gd.pitch + rx] = p;
