@@ -339,32 +339,41 @@ constexpr int kTPWide = 72, kTPNarrow = 48;
 // Strength A of the best 9-long arc: max over the 16 arcs of the minimum
 // signed contrast, both polarities.  A pixel is a FAST corner at threshold t
 // iff A > t, and cv::FAST's response is then A-1.  Both polarities run in one
-// packed 16-bit min chain on (v - p, p - v).
+// packed half-precision chain on (v - p, p - v): the integers -255 .. 255 are exact there, a byte b under the
+// exponent byte 0x64 is the half 1024 + b (so the contrasts come out of one packed subtraction with no conversion),
+// and gfx950 has three-operand packed minimum / maximum for halves, which the 16-bit integers lack.
 typedef short short2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 template <int kTP>
 __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
 {
-    const int v = c[0];
-    // (v - 255, -v) + (255 - p, p) = (v - p, p - v); 65535 * p + 255 packs (255 - p, p) without a borrow
-    const short2v cv = {(short)(v - 255), (short)(-v)};
-    int p[16];
+    const uint32_t v = c[0];
+    const half2v cv = __builtin_bit_cast(half2v, (0x6400u | v) | ((0xE400u | v) << 16));  // (1024 + v, -(1024 + v))
+    uint32_t p[16];
     p[0] = c[3 * kTP + 0];   p[1] = c[3 * kTP + 1];   p[2] = c[2 * kTP + 2];   p[3] = c[1 * kTP + 3];
     p[4] = c[0 * kTP + 3];   p[5] = c[-1 * kTP + 3];  p[6] = c[-2 * kTP + 2];  p[7] = c[-3 * kTP + 1];
     p[8] = c[-3 * kTP + 0];  p[9] = c[-3 * kTP - 1];  p[10] = c[-2 * kTP - 2]; p[11] = c[-1 * kTP - 3];
     p[12] = c[0 * kTP - 3];  p[13] = c[1 * kTP - 3];  p[14] = c[2 * kTP - 2];  p[15] = c[3 * kTP - 1];
-    short2v d[16], m2[16], m4[16], m8[16];
+    half2v d[16], m3[16], m9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = cv + __builtin_bit_cast(short2v, (uint32_t)p[k] * 65535u + 255u);
+    for (int k = 0; k < 16; k++) {
+        // (1024 + p, 1024 + p): the byte under 0x64 in both halves
+        const half2v x = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(0x64646464u, p[k], 0x04000400u));
+        d[k] = cv + (half2v){-x.x, x.y};  // (v - p, p - v)
+    }
+#define ORB_MIN3(a_, b_, c_) __builtin_elementwise_minimum(a_, __builtin_elementwise_minimum(b_, c_))
+#define ORB_MAX3(a_, b_, c_) __builtin_elementwise_maximum(a_, __builtin_elementwise_maximum(b_, c_))
 #pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+    for (int k = 0; k < 16; k++) m3[k] = ORB_MIN3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+    for (int k = 0; k < 16; k++) m9[k] = ORB_MIN3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);  // the arc k .. k+8
+    half2v best = ORB_MAX3(m9[0], m9[1], m9[2]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-    short2v best = {-256, -256};
-#pragma unroll
-    for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
-    return max((int)best.x, (int)best.y);
+    for (int k = 3; k < 15; k += 2) best = ORB_MAX3(best, m9[k], m9[k + 1]);
+    best = __builtin_elementwise_maximum(best, m9[15]);
+#undef ORB_MIN3
+#undef ORB_MAX3
+    return (int)fmaxf((float)best.x, (float)best.y);
 }
 
 // i / d for 0 <= i < 4096, 1 <= d <= 66, with m = ceil(2^20 / d)
