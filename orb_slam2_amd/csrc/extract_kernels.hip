@@ -504,8 +504,9 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     // arc contains one pixel of each opposite pair (k, k+8), so a corner needs the brighter of every even pair
     // below v - t or the darker of every even pair above v + t.  The ring bytes come out of 11 aligned dword
     // reads through byte permutes as 16-bit pairs (pixels 0|2 and 1|3 of the group), the test is packed 16-bit
-    // min / max / subtract and the verdicts are the sign bits.  Survivors go to a dense pixel queue for the
-    // arc evaluation.
+    // min / max / subtract and the verdicts are the sign bits: the 16-bit values are taken as half-precision
+    // denormals (a byte b is b * 2^-24; order, sums and differences of such values are exact), which have the
+    // three-operand packed minimum / maximum.  Survivors go to a dense pixel queue for the arc evaluation.
     const int t = G.minTh;
     const int mdiv = cu.mdiv;
     const uint8_t *t0 = cur + 1;  // pixel (x, y) of the cell image is t0[y * kTP + x]
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     const int ngx = (wi + 3) >> 2, ngroups = ngx * hi;  // groups of four interior pixels = dwords 1 .. ngx of a tile row
     const int mdivg = cu.mdivg;
     {
-        const short2v tt = __builtin_bit_cast(short2v, (uint32_t)t * 0x10001u);
+        const half2v tt = __builtin_bit_cast(half2v, (uint32_t)t * 0x10001u);
         constexpr int RP = kTP / 4;
         constexpr uint32_t kSel02 = 0x0c020c00u, kSel13 = 0x0c030c01u, kSel24 = 0x0c040c02u, kSel35 = 0x0c050c03u, kSel46 = 0x0c060c04u;
         for (int i = tid; i < ngroups; i += kFastThreads) {
@@ -531,16 +532,16 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
                 const uint32_t selp3 = odd ? kSel46 : kSel35;  // column +3 from (C1, C0)
                 const uint32_t selm3 = odd ? kSel24 : kSel13;  // column -3 from (C0, Cm)
                 const uint32_t selp2 = odd ? kSel35 : kSel24;  // column +2 from (x1, x0); column -2 from (x0, xm)
-#define ORB_P(hi_, lo_, sel_) __builtin_bit_cast(short2v, __builtin_amdgcn_perm(hi_, lo_, sel_))
-                const short2v v = ORB_P(0u, C0, selc), p0 = ORB_P(0u, P0, selc), p8 = ORB_P(0u, P8, selc);
-                const short2v p4 = ORB_P(C1, C0, selp3), p12 = ORB_P(C0, Cm, selm3);
-                const short2v p2 = ORB_P(B1, B0, selp2), p14 = ORB_P(B0, Bm, selp2);
-                const short2v p6 = ORB_P(A1, A0, selp2), p10 = ORB_P(A0, Am, selp2);
+#define ORB_P(hi_, lo_, sel_) __builtin_bit_cast(half2v, __builtin_amdgcn_perm(hi_, lo_, sel_))
+                const half2v v = ORB_P(0u, C0, selc), p0 = ORB_P(0u, P0, selc), p8 = ORB_P(0u, P8, selc);
+                const half2v p4 = ORB_P(C1, C0, selp3), p12 = ORB_P(C0, Cm, selm3);
+                const half2v p2 = ORB_P(B1, B0, selp2), p14 = ORB_P(B0, Bm, selp2);
+                const half2v p6 = ORB_P(A1, A0, selp2), p10 = ORB_P(A0, Am, selp2);
 #undef ORB_P
-#define ORB_MIN(a_, b_) __builtin_elementwise_min(a_, b_)
-#define ORB_MAX(a_, b_) __builtin_elementwise_max(a_, b_)
-                const short2v dmax = ORB_MAX(ORB_MAX(ORB_MIN(p0, p8), ORB_MIN(p4, p12)), ORB_MAX(ORB_MIN(p2, p10), ORB_MIN(p6, p14)));
-                const short2v bmin = ORB_MIN(ORB_MIN(ORB_MAX(p0, p8), ORB_MAX(p4, p12)), ORB_MIN(ORB_MAX(p2, p10), ORB_MAX(p6, p14)));
+#define ORB_MIN(a_, b_) __builtin_elementwise_minimum(a_, b_)
+#define ORB_MAX(a_, b_) __builtin_elementwise_maximum(a_, b_)
+                const half2v dmax = ORB_MAX(ORB_MAX(ORB_MIN(p0, p8), ORB_MIN(p4, p12)), ORB_MAX(ORB_MIN(p2, p10), ORB_MIN(p6, p14)));
+                const half2v bmin = ORB_MIN(ORB_MIN(ORB_MAX(p0, p8), ORB_MAX(p4, p12)), ORB_MIN(ORB_MAX(p2, p10), ORB_MAX(p6, p14)));
 #undef ORB_MIN
 #undef ORB_MAX
                 // dmax < v - t  or  bmin > v + t, as the signs of two differences (all values within +-510)
@@ -656,6 +657,14 @@ __device__ __forceinline__ int qn_count(const QNode &n) { return n.count & 0x7FF
 __device__ __forceinline__ int qn_buf(const QNode &n) { return (int)((uint32_t)n.count >> 31); }
 
 constexpr int kBigNode = 512;  // nodes above this many points are split by the whole workgroup
+constexpr int kQuadNode = 48;  // four nodes of at most this many points each share a wave, sixteen lanes per node
+
+// bits 16 g .. 16 g + 15 of a ballot: the lanes of sixteen-lane group g
+__device__ __forceinline__ uint32_t sub16(uint64_t b, int g)
+{
+    const uint32_t h = (g & 2) ? (uint32_t)(b >> 32) : (uint32_t)b;
+    return (h >> ((g & 1) << 4)) & 0xFFFFu;
+}
 
 struct OctCtx {
     uint32_t *buf0, *buf1;
@@ -692,23 +701,52 @@ __device__ int oct_count(const OctCtx &c, int cur, int nS)
         nB += total;
     }
     __syncthreads();
-    for (int e = wid; e < nS; e += nw) {
-        const QNode n = nl[c.S[e]];
-        const int cnt = qn_count(n);
-        if (cnt > kBigNode) continue;
-        const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
-        const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        for (int b = 0; b < cnt; b += 64) {
-            const int i = b + lane;
-            const int q = (i < cnt) ? quadrant_of(pts[i], midx, midy) : -1;
-            c0 += __popcll(__ballot(q == 0));
-            c1 += __popcll(__ballot(q == 1));
-            c2 += __popcll(__ballot(q == 2));
-            c3 += __popcll(__ballot(q == 3));
+    // small nodes: a wave takes four consecutive S entries.  While none of the four holds more than kQuadNode
+    // points (the late rounds: many nodes of a few points each) sixteen lanes work on each; otherwise the wave
+    // takes them one after the other.
+    for (int e0 = 4 * wid; e0 < nS; e0 += 4 * nw) {
+        const int grp = lane >> 4, sl = lane & 15, eg = e0 + grp;
+        QNode ng = {};
+        int cntg = 0;
+        if (eg < nS) {
+            ng = nl[c.S[eg]];
+            cntg = qn_count(ng);
         }
-        if (lane == 0) {
-            c.cnt4[4 * e + 0] = c0; c.cnt4[4 * e + 1] = c1; c.cnt4[4 * e + 2] = c2; c.cnt4[4 * e + 3] = c3;
+        if (__ballot(cntg > kQuadNode) == 0ull) {
+            const uint32_t *pts = c.buf(qn_buf(ng)) + ng.start;
+            const int midx = ng.x0 + ((ng.x1 - ng.x0 + 1) >> 1), midy = ng.y0 + ((ng.y1 - ng.y0 + 1) >> 1);
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int b = 0; __ballot(b < cntg) != 0ull; b += 16) {
+                const int i = b + sl;
+                const int q = (i < cntg) ? quadrant_of(pts[i], midx, midy) : -1;
+                c0 += __popc(sub16(__ballot(q == 0), grp));
+                c1 += __popc(sub16(__ballot(q == 1), grp));
+                c2 += __popc(sub16(__ballot(q == 2), grp));
+                c3 += __popc(sub16(__ballot(q == 3), grp));
+            }
+            if (sl == 0 && eg < nS) {
+                c.cnt4[4 * eg + 0] = c0; c.cnt4[4 * eg + 1] = c1; c.cnt4[4 * eg + 2] = c2; c.cnt4[4 * eg + 3] = c3;
+            }
+            continue;
+        }
+        for (int e = e0; e < min(e0 + 4, nS); e++) {
+            const QNode n = nl[c.S[e]];
+            const int cnt = qn_count(n);
+            if (cnt > kBigNode) continue;
+            const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
+            const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int b = 0; b < cnt; b += 64) {
+                const int i = b + lane;
+                const int q = (i < cnt) ? quadrant_of(pts[i], midx, midy) : -1;
+                c0 += __popcll(__ballot(q == 0));
+                c1 += __popcll(__ballot(q == 1));
+                c2 += __popcll(__ballot(q == 2));
+                c3 += __popcll(__ballot(q == 3));
+            }
+            if (lane == 0) {
+                c.cnt4[4 * e + 0] = c0; c.cnt4[4 * e + 1] = c1; c.cnt4[4 * e + 2] = c2; c.cnt4[4 * e + 3] = c3;
+            }
         }
     }
     for (int bi = 0; bi < nB; bi++) {
@@ -798,34 +836,73 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, in
         if (keep) c.nl(cur ^ 1)[nchild + carry + ex] = nl[i];
         carry += total;
     }
-    // scatter the points and emit the child nodes: small nodes, one wave each
-    for (int e = wid; e < nS; e += nw) {
-        const QNode n = nl[c.S[e]];
-        const int cnt = qn_count(n), sb = qn_buf(n), db = sb ^ 1;
-        if (cnt > kBigNode) continue;
-        const uint32_t *pts = c.buf(sb) + n.start;
-        uint32_t *dst = c.buf(db);
-        const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-        const int k0 = c.cnt4[4 * e + 0], k1 = c.cnt4[4 * e + 1], k2 = c.cnt4[4 * e + 2], k3 = c.cnt4[4 * e + 3];
-        const int s0 = n.start, s1 = s0 + k0, s2 = s1 + k1, s3 = s2 + k2;
-        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        const uint64_t lt = (1ull << lane) - 1ull;
-        for (int b = 0; b < cnt; b += 64) {
-            const int i = b + lane;
-            int q = -1;
-            uint32_t p = 0;
-            if (i < cnt) {
-                p = pts[i];
-                q = quadrant_of(p, midx, midy);
-            }
-            const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
-            if (q == 0) dst[s0 + r0 + __popcll(b0 & lt)] = p;
-            else if (q == 1) dst[s1 + r1 + __popcll(b1 & lt)] = p;
-            else if (q == 2) dst[s2 + r2 + __popcll(b2 & lt)] = p;
-            else if (q == 3) dst[s3 + r3 + __popcll(b3 & lt)] = p;
-            r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
+    // scatter the points and emit the child nodes.  Small nodes: four S entries per wave, sixteen lanes each
+    // while all four are small, else one after the other (as in oct_count)
+    for (int e0 = 4 * wid; e0 < nS; e0 += 4 * nw) {
+        const int grp = lane >> 4, sl = lane & 15, eg = e0 + grp;
+        QNode ng = {};
+        int cntg = 0;
+        if (eg < nS) {
+            ng = nl[c.S[eg]];
+            cntg = qn_count(ng);
         }
-        if (lane < 4) emit_child(c, cur, n, e, lane, midx, midy, k0, k1, k2, k3, s0, nchild, db);
+        if (__ballot(cntg > kQuadNode) == 0ull) {
+            const int sb = qn_buf(ng), db = sb ^ 1;
+            const uint32_t *pts = c.buf(sb) + ng.start;
+            uint32_t *dst = c.buf(db);
+            const int midx = ng.x0 + ((ng.x1 - ng.x0 + 1) >> 1), midy = ng.y0 + ((ng.y1 - ng.y0 + 1) >> 1);
+            int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+            if (eg < nS) { k0 = c.cnt4[4 * eg + 0]; k1 = c.cnt4[4 * eg + 1]; k2 = c.cnt4[4 * eg + 2]; k3 = c.cnt4[4 * eg + 3]; }
+            const int s0 = ng.start, s1 = s0 + k0, s2 = s1 + k1, s3 = s2 + k2;
+            int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            const uint32_t lt = (1u << sl) - 1u;
+            for (int b = 0; __ballot(b < cntg) != 0ull; b += 16) {
+                const int i = b + sl;
+                int q = -1;
+                uint32_t p = 0;
+                if (i < cntg) {
+                    p = pts[i];
+                    q = quadrant_of(p, midx, midy);
+                }
+                const uint32_t m0 = sub16(__ballot(q == 0), grp), m1 = sub16(__ballot(q == 1), grp), m2 = sub16(__ballot(q == 2), grp),
+                               m3 = sub16(__ballot(q == 3), grp);
+                if (q == 0) dst[s0 + r0 + __popc(m0 & lt)] = p;
+                else if (q == 1) dst[s1 + r1 + __popc(m1 & lt)] = p;
+                else if (q == 2) dst[s2 + r2 + __popc(m2 & lt)] = p;
+                else if (q == 3) dst[s3 + r3 + __popc(m3 & lt)] = p;
+                r0 += __popc(m0); r1 += __popc(m1); r2 += __popc(m2); r3 += __popc(m3);
+            }
+            if (sl < 4 && eg < nS) emit_child(c, cur, ng, eg, sl, midx, midy, k0, k1, k2, k3, s0, nchild, db);
+            continue;
+        }
+        for (int e = e0; e < min(e0 + 4, nS); e++) {
+            const QNode n = nl[c.S[e]];
+            const int cnt = qn_count(n), sb = qn_buf(n), db = sb ^ 1;
+            if (cnt > kBigNode) continue;
+            const uint32_t *pts = c.buf(sb) + n.start;
+            uint32_t *dst = c.buf(db);
+            const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+            const int k0 = c.cnt4[4 * e + 0], k1 = c.cnt4[4 * e + 1], k2 = c.cnt4[4 * e + 2], k3 = c.cnt4[4 * e + 3];
+            const int s0 = n.start, s1 = s0 + k0, s2 = s1 + k1, s3 = s2 + k2;
+            int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            const uint64_t lt = (1ull << lane) - 1ull;
+            for (int b = 0; b < cnt; b += 64) {
+                const int i = b + lane;
+                int q = -1;
+                uint32_t p = 0;
+                if (i < cnt) {
+                    p = pts[i];
+                    q = quadrant_of(p, midx, midy);
+                }
+                const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+                if (q == 0) dst[s0 + r0 + __popcll(b0 & lt)] = p;
+                else if (q == 1) dst[s1 + r1 + __popcll(b1 & lt)] = p;
+                else if (q == 2) dst[s2 + r2 + __popcll(b2 & lt)] = p;
+                else if (q == 3) dst[s3 + r3 + __popcll(b3 & lt)] = p;
+                r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
+            }
+            if (lane < 4) emit_child(c, cur, n, e, lane, midx, midy, k0, k1, k2, k3, s0, nchild, db);
+        }
     }
     // big nodes: the whole workgroup, stable ranks from two packed block scans per 1024 points
     for (int bi = 0; bi < nB; bi++) {
