@@ -354,13 +354,12 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
     p[4] = c[0 * kTP + 3];   p[5] = c[-1 * kTP + 3];  p[6] = c[-2 * kTP + 2];  p[7] = c[-3 * kTP + 1];
     p[8] = c[-3 * kTP + 0];  p[9] = c[-3 * kTP - 1];  p[10] = c[-2 * kTP - 2]; p[11] = c[-1 * kTP - 3];
     p[12] = c[0 * kTP - 3];  p[13] = c[1 * kTP - 3];  p[14] = c[2 * kTP - 2];  p[15] = c[3 * kTP - 1];
+    // min over an arc of (v - p, p - v) = (v, -v) + min over the arc of (-p, p): the ring goes in as
+    // (-(1024 + p), 1024 + p), the byte under the exponent bytes 0xE4 / 0x64 in one permute, and the centre is
+    // added once at the end
     half2v d[16], m3[16], m9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        // (1024 + p, 1024 + p): the byte under 0x64 in both halves
-        const half2v x = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(0x64646464u, p[k], 0x04000400u));
-        d[k] = cv + (half2v){-x.x, x.y};  // (v - p, p - v)
-    }
+    for (int k = 0; k < 16; k++) d[k] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(0x0000E464u, p[k], 0x04000500u));
 #define ORB_MIN3(a_, b_, c_) __builtin_elementwise_minimum(a_, __builtin_elementwise_minimum(b_, c_))
 #define ORB_MAX3(a_, b_, c_) __builtin_elementwise_maximum(a_, __builtin_elementwise_maximum(b_, c_))
 #pragma unroll
@@ -370,7 +369,7 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *c)
     half2v best = ORB_MAX3(m9[0], m9[1], m9[2]);
 #pragma unroll
     for (int k = 3; k < 15; k += 2) best = ORB_MAX3(best, m9[k], m9[k + 1]);
-    best = __builtin_elementwise_maximum(best, m9[15]);
+    best = __builtin_elementwise_maximum(best, m9[15]) + cv;
 #undef ORB_MIN3
 #undef ORB_MAX3
     return (int)fmaxf((float)best.x, (float)best.y);

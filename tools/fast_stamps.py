@@ -5,6 +5,8 @@ import sys, ctypes as C, numpy as np
 sys.path.insert(0, '.')
 import torch
 from orb_slam2_amd import api, synth
+if len(sys.argv) > 1:
+    api.LIB_PATH = sys.argv[1]  # a stamped build kept beside the product library
 dev = torch.device('cuda', 0)
 B = 512
 seq = synth.sequence(640, 480, 8, seed=1, per_frame_density=True)
