@@ -103,8 +103,10 @@ __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ i
 
 // cv::resize INTER_LINEAR 8UC1 fixed-point arithmetic (called at :1550) from
 // level l-1 into level l.  A workgroup produces a kRW x kRH output tile: the
-// source window of the tile is staged in LDS with coalesced 32-bit loads, then a
-// thread produces a 2 x 8 block of output pixels from LDS bytes.
+// source window of the tile is copied into LDS by direct global -> LDS loads (no
+// registers; a wave instruction fills 64 consecutive dwords of the window, rows of
+// rs_pitch_dw dwords), then a thread produces a 2 x 8 block of output pixels from LDS bytes.
+typedef __attribute__((address_space(3))) void rs_lvoid;
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, Geom G, int level,
                                                     const XTab *__restrict__ xtab, const YTab *__restrict__ ytab)
 {
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
     if (!frame_block(G.nimg, &f, &b)) return;
     const int tyi = b / tilesX, ty0 = tyi * kRH, tx0 = (b - tyi * tilesX) * kRW;
     const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const XTab *xt = xtab + gd.xtab_off;
     const YTab *yt = ytab + gd.ytab_off;
     // source window: columns sx_al .. (last tap + 1), rows sy_min .. sy1 of the last output row
@@ -125,32 +128,52 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
     const int nrows = yt[min(ty0 + kRH - 1, gd.h - 1)].sy1 - sy_min + 1;
     const int P = gd.rs_pitch_dw;
     uint8_t *base = pyr + (int64_t)f * G.pyr_frame_bytes;
-    const uint8_t *S = base + interior_off(gs) + (int64_t)sy_min * gs.pitch + sx_al;
-    const float inv_ndw = __fdiv_rn(1.0f, (float)ndw);
-    for (int i = tid; i < nrows * ndw; i += 256) {
-        const int r = (int)__fmul_rn((float)i + 0.5f, inv_ndw), c = i - r * ndw;  // exact: i < 2^16, ndw < 2^9
-        rs_src[r * P + c] = *reinterpret_cast<const uint32_t *>(S + (int64_t)r * gs.pitch + 4 * c);
+    const uint8_t *S = base + interior_off(gs) + (int64_t)sy_min * gs.pitch + sx_al;  // uniform, dword-aligned
+    {
+        // dword d of the window = (row d / P, column d % P); columns past the tile's last dword and rows past its last
+        // row re-read the last one (the buffer is padded to whole 64-dword pieces)
+        const int npieces = (nrows * P + 63) >> 6;
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(rs_lvoid *)rs_src);
+        const uint32_t magic = (uint32_t)gd.rs_magic;  // floor(2^32 / P) + 1: exact quotients for d * P < 2^32
+        for (int p = wv; p < npieces; p += 4) {
+            const uint32_t d = ((uint32_t)p << 6) + (uint32_t)lane;
+            const uint32_t r = __umulhi(d, magic), c = d - r * (uint32_t)P;
+            const uint32_t off = min(r, (uint32_t)(nrows - 1)) * (uint32_t)gs.pitch + 4u * min(c, (uint32_t)(ndw - 1));
+            const uint32_t dst = lds0 + ((uint32_t)p << 8);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(off), "s"(S), "s"(dst)
+                         : "memory");
+        }
     }
-    __syncthreads();
     // A wave produces 8 output rows x 128 columns, a lane 2 columns of each row.  The rows are uniform
     // over the wave, so the vertical tap table is scalar data and the horizontal sums of a source row,
-    // shared by consecutive output rows, are computed once and kept (rows A and B below).
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dx0 = tx0 + 2 * (tid & 63), dy0 = ty0 + 8 * wv;
-    if (dy0 >= gd.h) return;
-    const XTab t0 = xt[min(dx0, gd.w - 1)], t1 = xt[min(dx0 + 1, gd.w - 1)];
+    // shared by consecutive output rows, are computed once and kept (rows A and B below).  The tables are
+    // fetched while the window is on its way.
+    const int dx0 = tx0 + 2 * lane, dy0 = ty0 + 8 * wv;
+    const bool live = dy0 < gd.h;  // uniform
+    XTab t0 = {0, 0, 0}, t1 = {0, 0, 0};
+    YTab ytv[8];  // all eight (uniform) loads in flight at once
+    if (live) {
+        t0 = xt[min(dx0, gd.w - 1)];
+        t1 = xt[min(dx0 + 1, gd.w - 1)];
+#pragma unroll
+        for (int r = 0; r < 8; r++) ytv[r] = yt[min(dy0 + r, gd.h - 1)];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!live) return;
     // the right tap is the next byte: its weight is 0 where the reference clamps it
     const int xo0 = t0.sx - sx_al, xo1 = t1.sx - sx_al;
     int xr0 = xo0 + 1, xr1 = xo1 + 1;  // kept opaque: two byte reads, not one 16-bit read at an odd LDS address
     asm("" : "+v"(xr0), "+v"(xr1));
     const int a00 = t0.a0, a01 = t0.a1, a10 = t1.a0, a11 = t1.a1;
     const uint8_t *L = reinterpret_cast<const uint8_t *>(rs_src);
-    uint8_t *D = base + interior_off(gd) + dx0;  // this lane's column in row 0
+    uint8_t *D = base + interior_off(gd);  // uniform: row bases stay scalar, the lane adds its 32-bit column offset
+    const uint32_t dcol = (uint32_t)dx0;
     const int n = gd.w - dx0;  // columns of this lane inside the level: <= 0 none, 1 the first only
     int hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0;
-    YTab ytv[8];  // all eight (uniform) loads in flight at once
-#pragma unroll
-    for (int r = 0; r < 8; r++) ytv[r] = yt[min(dy0 + r, gd.h - 1)];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int y = dy0 + r;
@@ -175,13 +198,12 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
         const int p1 = (int)(__umulhi(B0, (uint32_t)hA1) + __umulhi(B1, (uint32_t)hB1) + 2u) >> 2;
         // the row and, for rows next to the top / bottom edge, its reflect-101 image in the halo (tabulated)
         const int ym = (yv.pad & 0xFFFF) - 32;
-        uint8_t *q = D + y * gd.pitch, *qm = D + ym * gd.pitch;  // 32-bit scalar row offsets (a frame's pyramid is < 2 GiB)
         if (n >= 1) {
             // an odd width's last lane also writes the first halo column (a copy of the last pixel): nothing in the
             // extraction reads it, and k_halo_sides overwrites it when a caller asks for the border
             const uint16_t v = (uint16_t)(p0 | (p1 << 8));
-            *reinterpret_cast<uint16_t *>(q) = v;
-            if (ym != y) *reinterpret_cast<uint16_t *>(qm) = v;
+            *reinterpret_cast<uint16_t *>(D + y * gd.pitch + dcol) = v;
+            if (ym != y) *reinterpret_cast<uint16_t *>(D + ym * gd.pitch + dcol) = v;
         }
     }
 }
@@ -1665,7 +1687,7 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
         hipLaunchKernelGGL(k_pyr_resize, frame_grid(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), nimg), dim3(256),
-                           (size_t)g.rs_rows * g.rs_pitch_dw * 4, st, pyr, G, l, xtab, ytab);
+                           ((size_t)g.rs_rows * g.rs_pitch_dw * 4 + 255) & ~(size_t)255, st, pyr, G, l, xtab, ytab);
     }
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;

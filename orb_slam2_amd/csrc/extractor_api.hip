@@ -336,6 +336,7 @@ if (g.node_cap > (1 << 20)) {
             }
             g.rs_rows = maxrows;
             g.rs_pitch_dw = maxdw | 1;
+            g.rs_magic = 0xFFFFFFFFu / (uint32_t)g.rs_pitch_dw + 1u;
             if ((int64_t)g.rs_rows * g.rs_pitch_dw * 4 > 64 * 1024) {
                 set_error("level %d: scale factor too large for the resize tile (%d x %d source dwords)", l, g.rs_rows, g.rs_pitch_dw);
                 return ORBGPU_E_UNSUPPORTED;
