@@ -535,9 +535,9 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     const int ngx = (wi + 3) >> 2, ngroups = ngx * hi;  // groups of four interior pixels = dwords 1 .. ngx of a tile row
     const int mdivg = cu.mdivg;
     {
-        const half2v tt = __builtin_bit_cast(half2v, (uint32_t)t * 0x10001u);
+        const uint32_t tg = ((uint32_t)t * 0x10001u) | 0x80008000u;  // the threshold under a guard bit in both halves
         constexpr int RP = kTP / 4;
-        constexpr uint32_t kSel02 = 0x0c020c00u, kSel13 = 0x0c030c01u, kSel24 = 0x0c040c02u, kSel35 = 0x0c050c03u, kSel46 = 0x0c060c04u;
+        constexpr uint32_t kSel13 = 0x0c030c01u, kSel24 = 0x0c040c02u, kSel35 = 0x0c050c03u, kSel46 = 0x0c060c04u;
         for (int i = tid; i < ngroups; i += kFastThreads) {
             const int y = div_small(i, mdivg), gx = i - (int)__umul24(y, ngx);
             // rows y .. y+6 of the tile, three dwords each; the group's pixels are the bytes of the middle dword of row y+3
@@ -549,12 +549,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
 #pragma unroll
             for (int odd = 0; odd < 2; odd++) {
                 // byte offsets of the ring from the group's first byte: pixels j = odd, odd + 2
-                const uint32_t selc = odd ? kSel13 : kSel02;   // column 0
                 const uint32_t selp3 = odd ? kSel46 : kSel35;  // column +3 from (C1, C0)
                 const uint32_t selm3 = odd ? kSel24 : kSel13;  // column -3 from (C0, Cm)
                 const uint32_t selp2 = odd ? kSel35 : kSel24;  // column +2 from (x1, x0); column -2 from (x0, xm)
 #define ORB_P(hi_, lo_, sel_) __builtin_bit_cast(half2v, __builtin_amdgcn_perm(hi_, lo_, sel_))
-                const half2v v = ORB_P(0u, C0, selc), p0 = ORB_P(0u, P0, selc), p8 = ORB_P(0u, P8, selc);
+                // column 0 needs no permute: bytes 0 | 2 or 1 | 3 of the dword by mask (and shift)
+#define ORB_C(x_) __builtin_bit_cast(half2v, ((odd ? (x_) >> 8 : (x_)) & 0x00FF00FFu))
+                const half2v v = ORB_C(C0), p0 = ORB_C(P0), p8 = ORB_C(P8);
+#undef ORB_C
                 const half2v p4 = ORB_P(C1, C0, selp3), p12 = ORB_P(C0, Cm, selm3);
                 const half2v p2 = ORB_P(B1, B0, selp2), p14 = ORB_P(B0, Bm, selp2);
                 const half2v p6 = ORB_P(A1, A0, selp2), p10 = ORB_P(A0, Am, selp2);
@@ -565,8 +567,12 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
                 const half2v bmin = ORB_MIN(ORB_MIN(ORB_MAX(p0, p8), ORB_MAX(p4, p12)), ORB_MIN(ORB_MAX(p2, p10), ORB_MAX(p6, p14)));
 #undef ORB_MIN
 #undef ORB_MAX
-                // dmax < v - t  or  bmin > v + t, as the signs of two differences (all values within +-510)
-                verdict[odd] = __builtin_bit_cast(uint32_t, dmax - (v - tt)) | __builtin_bit_cast(uint32_t, (v + tt) - bmin);
+                // dmax < v - t  or  bmin > v + t.  The halves are small non-negative integers, so the comparisons are
+                // plain 32-bit additions with a guard bit on top of each half (no borrow crosses the halves): bit 15 of
+                // a half of (dmax + t + 0x8000) - v is set unless dmax < v - t, likewise for (v + t + 0x8000) - bmin
+                const uint32_t vi = __builtin_bit_cast(uint32_t, v);
+                const uint32_t r1 = __builtin_bit_cast(uint32_t, dmax) + tg - vi, r2 = vi + tg - __builtin_bit_cast(uint32_t, bmin);
+                verdict[odd] = ~(r1 & r2);
             }
             const uint32_t S = (verdict[0] & 0x80008000u) | ((verdict[1] & 0x80008000u) >> 1);
             // bits 15 / 14 / 31 / 30 of S = pixels 0 / 1 / 2 / 3; pixels beyond the interior's last column were tested
@@ -1264,6 +1270,14 @@ __device__ __forceinline__ void blur_row4(uint32_t a, uint32_t b, uint32_t d, ui
     o[3] = __builtin_amdgcn_udot4(d, khi, __builtin_amdgcn_udot4(b, klo, 0u, false), false);
 }
 
+// {sat_u8(x[15:0]), sat_u8(x[31:16])} as the low 16 bits (signed 16-bit inputs saturate to 0 .. 255)
+__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t x)
+{
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(x));
+    return r & 0xFFFFu;
+}
+
 __device__ __forceinline__ uint32_t u4_at(const uint4 &v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
 
 // Horizontal pass of one tile straight from global memory (rows ty0-3 .. ty0+kBH+2, clamped into the halo): a
@@ -1362,16 +1376,17 @@ __global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict
 #pragma unroll
     for (int rr = 0; rr < 8; rr++) {
         const int b = rr >> 1;
-        uint32_t packed = 0;
+        uint32_t sacc[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t p0 = u4_at(h[b], q), p1 = u4_at(h[b + 1], q), p2 = u4_at(h[b + 2], q), p3 = u4_at(h[b + 3], q);
-            uint32_t sacc;
-            if (rr & 1) sacc = dot2_u16(p3, wo3, dot2_u16(p2, wo2, dot2_u16(p1, wo1, dot2_u16(p0, wo0, 32768u))));
-            else sacc = dot2_u16(p3, we3, dot2_u16(p2, we2, dot2_u16(p1, we1, dot2_u16(p0, we0, 32768u))));
-            packed |= min(sacc >> 16, 255u) << (8 * q);
+            if (rr & 1) sacc[q] = dot2_u16(p3, wo3, dot2_u16(p2, wo2, dot2_u16(p1, wo1, dot2_u16(p0, wo0, 32768u))));
+            else sacc[q] = dot2_u16(p3, we3, dot2_u16(p2, we2, dot2_u16(p1, we1, dot2_u16(p0, we0, 32768u))));
         }
-        rows8[rr] = packed;
+        // the four results are the high halves (<= 257 with the 49 / 55 taps): two permutes gather them as 16-bit
+        // pairs, the pack instruction saturates each pair into two bytes
+        rows8[rr] = sat_pk_u8(__builtin_amdgcn_perm(sacc[1], sacc[0], 0x07060302u)) |
+                    (sat_pk_u8(__builtin_amdgcn_perm(sacc[3], sacc[2], 0x07060302u)) << 16);
     }
     // the thread's 4 columns x 8 rows are 32 contiguous bytes of a tile (the first row is a multiple of 8); rows past
     // the level's last one and the up to 3 columns past its width land in unused bytes of the level's block
