@@ -968,7 +968,7 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, in
     *out_expand = nexp;
 }
 
-__device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__restrict__ slots,
+__device__ __forceinline__ void octree_level(const int level, const int f, const Geom &G, const uint32_t *__restrict__ slots,
                                              const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,
                                              int32_t *scratch, uint32_t *__restrict__ sel,
                                              int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,
@@ -987,7 +987,7 @@ __device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__re
     __shared__ int root_cnt[kMaxRoots], root_start[kMaxRoots];
     __shared__ int sh_a, lds4[4];
 
-    const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const LevelGeom &g = G.lv[level];
     const int N = g.quota;
     OctCtx c;
@@ -1234,13 +1234,16 @@ __device__ __forceinline__ void octree_level(const Geom &G, const uint32_t *__re
 // one frame: a few 1024-thread workgroups, each with most of a CU's LDS (candidate buffers included)
 __global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
 {
-    octree_level(G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, dyn_coff_off, pts_cap,
-                 dyn_pts_off);
+    octree_level(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes,
+                 dyn_coff_off, pts_cap, dyn_pts_off);
 }
-// a batch: 256-thread workgroups, registers capped so that eight of them share a CU
+// a batch: 256-thread workgroups, registers capped so that eight of them share a CU.  The grid is (frames, levels):
+// workgroups start in linear order, so the levels with the most candidates (the lowest) start first and the short
+// ones fill the tail.
 __global__ __launch_bounds__(256, 8) void k_octree_batch(OCTREE_ARGS)
 {
-    octree_level(G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, dyn_coff_off, 0, 0);
+    octree_level(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes,
+                 dyn_coff_off, 0, 0);
 }
 #undef OCTREE_ARGS
 
@@ -1778,7 +1781,7 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
     size_t dyn = coff_off + (size_t)(threads + 1) * 4;
     if (nimg * G.nlevels >= 256) {
-        hipLaunchKernelGGL(k_octree_batch, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch,
+        hipLaunchKernelGGL(k_octree_batch, dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch,
                            sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, 0, 0);
     } else {
         // the two candidate buffers of a level in LDS too, as far as 144 KiB go (a workgroup may use the whole CU's)
