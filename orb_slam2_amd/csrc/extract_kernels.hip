@@ -968,11 +968,12 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, in
     *out_expand = nexp;
 }
 
+template <bool kLdsNodes>
 __device__ __forceinline__ void octree_level(const int level, const int f, const Geom &G, const uint32_t *__restrict__ slots,
                                              const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,
                                              int32_t *scratch, uint32_t *__restrict__ sel,
                                              int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,
-                                             int32_t *__restrict__ status, int keys_cap, int lds_nodes, int dyn_coff_off,
+                                             int32_t *__restrict__ status, int keys_cap, int dyn_coff_off,
                                              int pts_cap, int dyn_pts_off)
 {
     // dynamic LDS: keys_cap 64-bit sort keys, then (lds_nodes != 0) the node
@@ -993,16 +994,10 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
     OctCtx c;
     c.buf0 = cand + (int64_t)f * G.cand_frame_u32 + g.cand_off;
     c.buf1 = c.buf0 + g.cand_cap;
-    c.nl0 = nodes + (int64_t)f * G.node_frame + g.node_off;
-    c.nl1 = c.nl0 + g.node_cap;
-    int32_t *scr = scratch + ((int64_t)f * G.node_frame + g.node_off) * kScratchPerNode;  // 12 * node_cap words
-    if (keys_cap == 0) keys = reinterpret_cast<unsigned long long *>(scr + 8 * g.node_cap);  // 2 * node_cap keys
-    c.S = scr;
-    c.cnt4 = scr + g.node_cap;
-    c.cbase = scr + 5 * g.node_cap;
-    c.mark = scr + 6 * g.node_cap;
-    c.big = scr + 7 * g.node_cap;
-    if (lds_nodes) {
+    // kLdsNodes: the node lists and work lists are in LDS, and this instance derives their pointers from the LDS
+    // array alone, so that every access compiles to an LDS instruction (a pointer that may be either, decided at
+    // run time, makes them flat accesses: longer latency, and they tie the LDS and the vector-memory counters)
+    if constexpr (kLdsNodes) {
         c.nl0 = reinterpret_cast<QNode *>(dyn_lds + (size_t)keys_cap * 8);
         c.nl1 = c.nl0 + g.node_cap;
         int32_t *ip = reinterpret_cast<int32_t *>(c.nl1 + g.node_cap);
@@ -1011,6 +1006,16 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
         c.cbase = ip + 5 * g.node_cap;
         c.mark = ip + 6 * g.node_cap;
         c.big = ip + 7 * g.node_cap;
+    } else {
+        c.nl0 = nodes + (int64_t)f * G.node_frame + g.node_off;
+        c.nl1 = c.nl0 + g.node_cap;
+        int32_t *scr = scratch + ((int64_t)f * G.node_frame + g.node_off) * kScratchPerNode;  // 12 * node_cap words
+        if (keys_cap == 0) keys = reinterpret_cast<unsigned long long *>(scr + 8 * g.node_cap);  // 2 * node_cap keys
+        c.S = scr;
+        c.cnt4 = scr + g.node_cap;
+        c.cbase = scr + 5 * g.node_cap;
+        c.mark = scr + 6 * g.node_cap;
+        c.big = scr + 7 * g.node_cap;
     }
     c.scan_lds = scan_lds;
     c.lds4 = lds4;
@@ -1234,16 +1239,24 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
 // one frame: a few 1024-thread workgroups, each with most of a CU's LDS (candidate buffers included)
 __global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
 {
-    octree_level(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes,
-                 dyn_coff_off, pts_cap, dyn_pts_off);
+    if (lds_nodes)
+        octree_level<true>(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                           dyn_coff_off, pts_cap, dyn_pts_off);
+    else
+        octree_level<false>(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                            dyn_coff_off, pts_cap, dyn_pts_off);
 }
 // a batch: 256-thread workgroups, registers capped so that eight of them share a CU.  The grid is (frames, levels):
 // workgroups start in linear order, so the levels with the most candidates (the lowest) start first and the short
 // ones fill the tail.
 __global__ __launch_bounds__(256, 8) void k_octree_batch(OCTREE_ARGS)
 {
-    octree_level(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes,
-                 dyn_coff_off, 0, 0);
+    if (lds_nodes)
+        octree_level<true>(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                           dyn_coff_off, 0, 0);
+    else
+        octree_level<false>(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                            dyn_coff_off, 0, 0);
 }
 #undef OCTREE_ARGS
 
