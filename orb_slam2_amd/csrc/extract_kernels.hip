@@ -524,10 +524,11 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     // stage 1: cheap rejection at the lower threshold, four horizontally adjacent pixels per lane: any 9-long
     // arc contains one pixel of each opposite pair (k, k+8), so a corner needs the brighter of every even pair
     // below v - t or the darker of every even pair above v + t.  The ring bytes come out of 11 aligned dword
-    // reads through byte permutes as 16-bit pairs (pixels 0|2 and 1|3 of the group), the test is packed 16-bit
-    // min / max / subtract and the verdicts are the sign bits: the 16-bit values are taken as half-precision
-    // denormals (a byte b is b * 2^-24; order, sums and differences of such values are exact), which have the
-    // three-operand packed minimum / maximum.  Survivors go to a dense pixel queue for the arc evaluation.
+    // reads through byte permutes (column 0: a mask) as 16-bit pairs (pixels 0|2 and 1|3 of the group), the test is
+    // packed 16-bit min / max: the 16-bit values are taken as half-precision denormals (a byte b is b * 2^-24; the
+    // order of such values is that of the bytes), which have the three-operand packed minimum / maximum; the two
+    // comparisons with v -+ t are 32-bit integer additions under guard bits.  Survivors go to a dense pixel queue
+    // for the arc evaluation.
     const int t = G.minTh;
     const int mdiv = cu.mdiv;
     const uint8_t *t0 = cur + 1;  // pixel (x, y) of the cell image is t0[y * kTP + x]

@@ -84,3 +84,13 @@ def test_opencv_branch_of_the_headers_type_checks():
     subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-fsyntax-only",
                            "-I" + os.path.join(ROOT, "tests", "cpp", "fake_opencv"), "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "opencv_branch_probe.cc")])
+
+
+def test_resize_window_row_reciprocal_is_exact():
+    """The resize kernel finds the row of a staged source dword as the high word of d * (floor(2^32 / P) + 1)
+    (extractor_api.hip sets the multiplier per level): exact for every window the library admits (at most 64 KiB,
+    i.e. d < 2^14, and any dword pitch)."""
+    d = np.arange(1 << 14, dtype=np.uint64)
+    for P in list(range(1, 600)) + [1023, 4095, 16383]:
+        magic = np.uint64(0xFFFFFFFF // P + 1)
+        assert np.array_equal((d * magic) >> np.uint64(32), d // np.uint64(P)), P
