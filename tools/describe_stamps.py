@@ -9,10 +9,12 @@ import numpy as np
 sys.path.insert(0, ".")
 import torch  # noqa: E402
 from orb_slam2_amd import api, synth  # noqa: E402
+if len(sys.argv) > 1:
+    api.LIB_PATH = sys.argv[1]  # a stamped build kept beside the product library
 
 dev = torch.device("cuda", 0)
 B = 512
-seq = synth.sequence(640, 480, 8, seed=1)
+seq = synth.sequence(640, 480, 8, seed=1, per_frame_density=True)
 d = torch.from_numpy(np.ascontiguousarray(np.tile(seq, (B // 8, 1, 1)))).to(dev)
 ex = api.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=B)
 cap = ex.max_keypoints
