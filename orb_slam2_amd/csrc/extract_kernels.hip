@@ -352,7 +352,6 @@ __global__ __launch_bounds__(1024) void k_pyr_fused(uint8_t *__restrict__ pyr, G
 constexpr int kStampWgs = 1 << 19;
 __device__ unsigned g_fast_stamps[8 * kStampWgs];
 #endif
-constexpr int kFastThreads = 128;  // threads of a FAST workgroup
 // LDS tile pitch in bytes, a template parameter of the FAST kernels: 72 (18 dwords: one lead byte + a 66 px row, rounded
 // up) holds every cell the reference can make; 48 holds cell images up to 44 px wide (grids of ~30 px cells on levels
 // wider than a few cells, the usual case) in two thirds of the LDS and of the copy's instructions.
@@ -468,18 +467,18 @@ __device__ __forceinline__ void fast_stage_cell(const FastCell &c, uint8_t *buf,
 }
 __device__ __forceinline__ void fast_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int kTP>
+template <int kTP, int kFastThreads>
 __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G, const uint32_t *__restrict__ cell_tab,
                                                     uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts,
-                                                    int cells_per_wg, int lds_tile_bytes, int lds_score_off, int lds_maxima_off,
-                                                    int lds_queue_off)
+                                                    int cells_per_wg, int lds_score_off, int SP, int lds_queue_off)
 {
     // dynamic LDS, sized by the launcher for the largest cell of the geometry:
-    // tile x 2 | score (interior + 1 px zero border) | maxima | queue
+    // tile | score (interior + 1 px zero border, rows of SP bytes) | queue; the list of maxima takes the tile's place
+    // once the arc stage has read it for the last time
     extern __shared__ __align__(16) uint8_t fast_lds[];
     uint8_t *tile = fast_lds;
     uint8_t *score = tile + lds_score_off;
-    uint32_t *maxima = reinterpret_cast<uint32_t *>(tile + lds_maxima_off);  // strict 3x3 maxima are never adjacent
+    uint32_t *maxima = reinterpret_cast<uint32_t *>(tile);  // strict 3x3 maxima are never adjacent: at most a quarter of the pixels
     uint16_t *queue = reinterpret_cast<uint16_t *>(tile + lds_queue_off);
     __shared__ int qn, nmax, nini;
 #ifdef ORBGPU_STAMPS
@@ -490,36 +489,31 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
 #define ORB_STAMP(k_) do { } while (0)
 #endif
 
-    // A workgroup searches cells_per_wg consecutive cells (horizontal neighbours: they share 128-byte lines of the
-    // pyramid).  While one cell is searched in one tile buffer the next is copied into the other, so the
-    // global-memory latency of the staging is paid once per workgroup, not once per cell.
+    // A workgroup searches cells_per_wg consecutive cells, one after the other.  In batches it is a single wave (the
+    // barriers below then cost nothing) with little LDS, so that a CU holds many of them and the wait of one for its
+    // cell image is filled by the others; a second tile buffer that prefetches the next cell and a second wave
+    // measured slower (fewer workgroups per CU, waves idling at the barriers between the stages).
     const int f = blockIdx.y, tid = threadIdx.x;
     const int cell0 = blockIdx.x * cells_per_wg;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    FastCell nx = fast_cell_info(pyr, G, cell_tab, f, cell0);
-    if (nx.state == 2) fast_stage_cell<kTP>(nx, tile, wave, lane, kFastThreads / 64);
 #pragma unroll 1
     for (int k = 0; k < cells_per_wg; k++) {
-        const FastCell cu = nx;
-        if (cu.state == 0) break;
         const int cell = cell0 + k;
+        const FastCell cu = fast_cell_info(pyr, G, cell_tab, f, cell);
+        if (cu.state == 0) break;
         int32_t *cnt_out = cell_counts + (int64_t)f * G.total_cells + cell;
-        uint8_t *cur = tile + (k & 1) * lds_tile_bytes, *nxt = tile + ((k + 1) & 1) * lds_tile_bytes;
-        if (k + 1 < cells_per_wg) nx = fast_cell_info(pyr, G, cell_tab, f, cell + 1);
-        else nx.state = 0;
+        uint8_t *cur = tile;
         if (cu.state == 1) {
             if (tid == 0) *cnt_out = 0;
-            // the other buffer was last read before the barrier that ended the previous cell
-            if (nx.state == 2) fast_stage_cell<kTP>(nx, nxt, wave, lane, kFastThreads / 64);
             continue;
         }
         const int wi = cu.cw - 6, hi = cu.ch - 6;
-    for (int i = tid; i < ((hi + 2) * (kTP / 4) + 3) / 4; i += kFastThreads) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+    fast_stage_cell<kTP>(cu, cur, wave, lane, kFastThreads / 64);
+    for (int i = tid; i < ((hi + 2) * SP + 15) >> 4; i += kFastThreads) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) { qn = 0; nmax = 0; nini = 0; }
-    fast_stage_wait();  // the first cell's copy (later cells were waited for below)
+    fast_stage_wait();
     __syncthreads();
     ORB_STAMP(1);
-    if (nx.state == 2) fast_stage_cell<kTP>(nx, nxt, wave, lane, kFastThreads / 64);  // lands during the rejection stage
 
     // stage 1: cheap rejection at the lower threshold, four horizontally adjacent pixels per lane: any 9-long
     // arc contains one pixel of each opposite pair (k, k+8), so a corner needs the brighter of every even pair
@@ -606,7 +600,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
         const int i = queue[q];
         const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
         const int A = fast_arc_strength<kTP>(t0 + (y + 3) * kTP + (x + 3));
-        if (A > t) score[(y + 1) * kTP + (x + 1)] = (uint8_t)(A - 1);
+        if (A > t) score[(y + 1) * SP + (x + 1)] = (uint8_t)(A - 1);
     }
     __syncthreads();
     ORB_STAMP(4);
@@ -615,11 +609,11 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     for (int q = tid; q < nq; q += kFastThreads) {
         const int i = queue[q];
         const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
-        const uint8_t *s = score + (y + 1) * kTP + (x + 1);
+        const uint8_t *s = score + (y + 1) * SP + (x + 1);
         const int sc = s[0];
         if (sc == 0) continue;
-        const int nb = max(max(max((int)s[-1], (int)s[1]), max((int)s[-kTP - 1], (int)s[-kTP])),
-                           max(max((int)s[-kTP + 1], (int)s[kTP - 1]), max((int)s[kTP], (int)s[kTP + 1])));
+        const int nb = max(max(max((int)s[-1], (int)s[1]), max((int)s[-SP - 1], (int)s[-SP])),
+                           max(max((int)s[-SP + 1], (int)s[SP - 1]), max((int)s[SP], (int)s[SP + 1])));
         if (sc > nb) {
             const int ini = sc >= G.iniTh ? 1 : 0;
             maxima[atomicAdd(&nmax, 1)] = (uint32_t)i | ((uint32_t)ini << 12) | ((uint32_t)sc << 16);
@@ -663,8 +657,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
         if (pos < cu.cell_cap) slot[pos] = pack_cand(x + cu.x0, y + cu.y0, (int)(e >> 16));
     }
     if (tid == 0) *cnt_out = min(count, cu.cell_cap);
-    fast_stage_wait();  // the next cell's copy: every wave waits for its own pieces, the barrier joins them
-    __syncthreads();    // the next cell also reuses the score plane and the counters
+    __syncthreads();  // the next cell reuses the tile (the maxima), the score plane and the counters
     ORB_STAMP(6);
     }
 }
@@ -1763,19 +1756,25 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
     // a tile row holds the cell image (cell + 6) behind one lead byte, in whole dwords
     const int kTP = wmax + 6 + 4 <= kTPNarrow ? kTPNarrow : kTPWide;
     const int tile_bytes = ((hmax + 6) * kTP + 255) & ~255;  // whole 64-dword pieces of the direct global -> LDS copy
-    const int score_off = 2 * tile_bytes, maxima_off = score_off + (((hmax + 2) * kTP + 15) & ~15);
-    const int queue_off = maxima_off + ((((wmax + 1) / 2) * ((hmax + 1) / 2) * 4 + 15) & ~15);
+    const int score_pitch = (wmax + 2 + 3) & ~3, score_off = tile_bytes;
+    const int queue_off = score_off + (((hmax + 2) * score_pitch + 15) & ~15);
     const size_t lds = (size_t)queue_off + (size_t)wmax * hmax * 2;
-    // runs of cells per workgroup hide the staging latency when there are many more workgroups than the chip
-    // holds at once; with a few frames the cells are better spread over all CUs
-    const int per_wg = (int64_t)G.total_cells * nimg >= 16384 ? kFastQuad : 1;
+    // A batch: one wave per workgroup and runs of cells, so that a CU holds as many independent workgroups as its
+    // LDS allows; a few frames: the cells spread over all CUs, two waves on each
+    const bool batch = (int64_t)G.total_cells * nimg >= 16384;
+    const int per_wg = batch ? kFastQuad : 1;
     const dim3 grid((G.total_cells + per_wg - 1) / per_wg, nimg);
-    if (kTP == kTPNarrow)
-        hipLaunchKernelGGL(k_fast_cells<kTPNarrow>, grid, dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots, cell_counts, per_wg, tile_bytes,
-                           score_off, maxima_off, queue_off);
-    else
-        hipLaunchKernelGGL(k_fast_cells<kTPWide>, grid, dim3(kFastThreads), lds, st, pyr, G, cell_tab, slots, cell_counts, per_wg, tile_bytes,
-                           score_off, maxima_off, queue_off);
+#define ORB_FAST_LAUNCH(tp_, th_)                                                                                                     \
+    hipLaunchKernelGGL((k_fast_cells<tp_, th_>), grid, dim3(th_), lds, st, pyr, G, cell_tab, slots, cell_counts, per_wg, score_off, \
+                       score_pitch, queue_off)
+    if (kTP == kTPNarrow) {
+        if (batch) ORB_FAST_LAUNCH(kTPNarrow, 64);
+        else ORB_FAST_LAUNCH(kTPNarrow, 128);
+    } else {
+        if (batch) ORB_FAST_LAUNCH(kTPWide, 64);
+        else ORB_FAST_LAUNCH(kTPWide, 128);
+    }
+#undef ORB_FAST_LAUNCH
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
