@@ -470,7 +470,7 @@ __device__ __forceinline__ void fast_stage_wait() { asm volatile("s_waitcnt vmcn
 template <int kTP, int kFastThreads>
 __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom G, const uint32_t *__restrict__ cell_tab,
                                                     uint32_t *__restrict__ slots, int32_t *__restrict__ cell_counts,
-                                                    int cells_per_wg, int lds_score_off, int SP, int lds_queue_off)
+                                                    int cells_per_wg, int lds_score_off, int SP, int lds_queue_off, int qcap)
 {
     // dynamic LDS, sized by the launcher for the largest cell of the geometry:
     // tile | score (interior + 1 px zero border, rows of SP bytes) | queue; the list of maxima takes the tile's place
@@ -585,19 +585,26 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
                 if (lane_id() == __ffsll((long long)act) - 1) base = atomicAdd(&qn, n0 + n1 + n2 + n3);
                 base = __builtin_amdgcn_readfirstlane(base);
 #define ORB_RANK(m_) (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m_) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m_), 0u))
-                if (s0) queue[base + ORB_RANK(m0)] = (uint16_t)pix0;
-                if (s1) queue[base + n0 + ORB_RANK(m1)] = (uint16_t)(pix0 + 1);
-                if (s2) queue[base + n0 + n1 + ORB_RANK(m2)] = (uint16_t)(pix0 + 2);
-                if (s3) queue[base + n0 + n1 + n2 + ORB_RANK(m3)] = (uint16_t)(pix0 + 3);
+                // entries past the queue's capacity are dropped: the cell is then evaluated densely (below)
+                const int q0 = base + ORB_RANK(m0), q1 = base + n0 + ORB_RANK(m1), q2 = base + n0 + n1 + ORB_RANK(m2),
+                          q3 = base + n0 + n1 + n2 + ORB_RANK(m3);
+                if (s0 && q0 < qcap) queue[q0] = (uint16_t)pix0;
+                if (s1 && q1 < qcap) queue[q1] = (uint16_t)(pix0 + 1);
+                if (s2 && q2 < qcap) queue[q2] = (uint16_t)(pix0 + 2);
+                if (s3 && q3 < qcap) queue[q3] = (uint16_t)(pix0 + 3);
 #undef ORB_RANK
             }
         }
     }
     __syncthreads();
     ORB_STAMP(2);
-    const int nq = qn;
+    // The queue holds qcap entries, which keeps the workgroup's LDS small enough for a CU to hold 32 of them; a cell
+    // with more survivors (noise at a low threshold) is evaluated densely instead, every pixel of it: the arc score
+    // decides alone, so the result is the same.
+    const bool dense = qn > qcap;  // uniform
+    const int nq = dense ? (int)__umul24(wi, hi) : qn;
     for (int q = tid; q < nq; q += kFastThreads) {
-        const int i = queue[q];
+        const int i = dense ? q : (int)queue[q];
         const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
         const int A = fast_arc_strength<kTP>(t0 + (y + 3) * kTP + (x + 3));
         if (A > t) score[(y + 1) * SP + (x + 1)] = (uint8_t)(A - 1);
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     // stage 2: strict 3x3 maximum inside the cell, evaluated for the corners only;
     // a maximum is listed as pixel index | initial-threshold flag << 12 | score << 16
     for (int q = tid; q < nq; q += kFastThreads) {
-        const int i = queue[q];
+        const int i = dense ? q : (int)queue[q];
         const int y = div_small(i, mdiv), x = i - (int)__umul24(y, wi);
         const uint8_t *s = score + (y + 1) * SP + (x + 1);
         const int sc = s[0];
@@ -1758,7 +1765,18 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
     const int tile_bytes = ((hmax + 6) * kTP + 255) & ~255;  // whole 64-dword pieces of the direct global -> LDS copy
     const int score_pitch = (wmax + 2 + 3) & ~3, score_off = tile_bytes;
     const int queue_off = score_off + (((hmax + 2) * score_pitch + 15) & ~15);
-    const size_t lds = (size_t)queue_off + (size_t)wmax * hmax * 2;
+    // the survivor queue: all pixels of the largest cell if that keeps the workgroup within a 32nd of a CU's LDS (5120
+    // bytes, 16 of them static), else what is left of that share but at least 256 entries
+    constexpr int kLdsShare = 160 * 1024 / 32 - 16;
+    int qcap = wmax * hmax;
+    if (queue_off + 2 * qcap > kLdsShare) qcap = (kLdsShare - queue_off) / 2 > 256 ? (kLdsShare - queue_off) / 2 : 256;
+    if (qcap > wmax * hmax) qcap = wmax * hmax;
+    // test hook: a smaller queue sends ordinary cells down the dense path (tests/test_gpu_extract.py)
+    if (const char *ov = getenv("ORBGPU_FAST_QUEUE_CAP")) {
+        const int v = atoi(ov);
+        if (v >= 1 && v < qcap) qcap = v;
+    }
+    const size_t lds = (size_t)queue_off + (size_t)qcap * 2;
     // A batch: one wave per workgroup and runs of cells, so that a CU holds as many independent workgroups as its
     // LDS allows; a few frames: the cells spread over all CUs, two waves on each
     const bool batch = (int64_t)G.total_cells * nimg >= 16384;
@@ -1766,7 +1784,7 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
     const dim3 grid((G.total_cells + per_wg - 1) / per_wg, nimg);
 #define ORB_FAST_LAUNCH(tp_, th_)                                                                                                     \
     hipLaunchKernelGGL((k_fast_cells<tp_, th_>), grid, dim3(th_), lds, st, pyr, G, cell_tab, slots, cell_counts, per_wg, score_off, \
-                       score_pitch, queue_off)
+                       score_pitch, queue_off, qcap)
     if (kTP == kTPNarrow) {
         if (batch) ORB_FAST_LAUNCH(kTPNarrow, 64);
         else ORB_FAST_LAUNCH(kTPNarrow, 128);

@@ -524,3 +524,30 @@ def test_quadtree_tie_rule_is_locked(oracle):
         other = set(zip(akps["x"].tolist(), akps["y"].tolist(), akps["octave"].tolist()))
         seen += len(mine - other)
     assert seen > 0  # the other order selects different keypoints: the rule is what the equality above pins
+
+
+def test_fast_dense_path_when_the_survivor_queue_overflows(oracle, monkeypatch):
+    """The FAST kernel's survivor queue is bounded (so that a CU holds 32 of its workgroups); a cell with more
+    survivors is evaluated densely, every pixel of it.  With the queue capped at 24 entries (ORBGPU_FAST_QUEUE_CAP, a
+    test hook read at every launch) nearly every cell takes that path, in the two-wave single-frame kernel and in
+    the one-wave batch kernel: candidates (order included) and the extraction equal the oracle's, noise included."""
+    monkeypatch.setenv("ORBGPU_FAST_QUEUE_CAP", "24")
+    rng = np.random.default_rng(3)
+    seq = synth.sequence(640, 480, 24, seed=8, per_frame_density=True)
+    seq[5] = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    oe = oracle.Extractor(1000)
+    one = _mk(640, 480, 1000)
+    for i in (0, 5):
+        _compare(one, oe, seq[i])
+        for level in (0, 3, 7):
+            gx, gy, gr = one.debug_level_candidates(level)
+            cx, cy, cr = oracle.level_candidates(oe.level(level))
+            assert np.array_equal(gx, cx.astype(np.int32)) and np.array_equal(gy, cy.astype(np.int32)), (i, level)
+            assert np.array_equal(gr, cr.astype(np.int32)), (i, level)
+    ex = _mk(640, 480, 1000, max_batch=24)  # 24 x 815 cells: the batch kernel
+    res = ex.extract_batch(seq)
+    monkeypatch.delenv("ORBGPU_FAST_QUEUE_CAP")
+    ref = _mk(640, 480, 1000)
+    for i in range(24):
+        k1, d1 = ref(seq[i])
+        assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1), "frame %d" % i
