@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ i
 // registers; a wave instruction fills 64 consecutive dwords of the window, rows of
 // rs_pitch_dw dwords), then a thread produces a 2 x 8 block of output pixels from LDS bytes.
 typedef __attribute__((address_space(3))) void rs_lvoid;
-__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, Geom G, int level,
+__global__ __launch_bounds__(kRH / 8 * 64) void k_pyr_resize(uint8_t *__restrict__ pyr, Geom G, int level,
                                                     const XTab *__restrict__ xtab, const YTab *__restrict__ ytab)
 {
     extern __shared__ __align__(16) uint32_t rs_src[];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, G
         const int npieces = (nrows * P + 63) >> 6;
         const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(rs_lvoid *)rs_src);
         const uint32_t magic = (uint32_t)gd.rs_magic;  // floor(2^32 / P) + 1: exact quotients for d * P < 2^32
-        for (int p = wv; p < npieces; p += 4) {
+        for (int p = wv; p < npieces; p += kRH / 8) {
             const uint32_t d = ((uint32_t)p << 6) + (uint32_t)lane;
             const uint32_t r = __umulhi(d, magic), c = d - r * (uint32_t)P;
             const uint32_t off = min(r, (uint32_t)(nrows - 1)) * (uint32_t)gs.pitch + 4u * min(c, (uint32_t)(ndw - 1));
@@ -1718,7 +1718,7 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     }
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &g = G.lv[l];
-        hipLaunchKernelGGL(k_pyr_resize, frame_grid(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), nimg), dim3(256),
+        hipLaunchKernelGGL(k_pyr_resize, frame_grid(((g.w + kRW - 1) / kRW) * ((g.h + kRH - 1) / kRH), nimg), dim3(kRH / 8 * 64),
                            ((size_t)g.rs_rows * g.rs_pitch_dw * 4 + 255) & ~(size_t)255, st, pyr, G, l, xtab, ytab);
     }
     ORBGPU_HIP_CHECK(hipGetLastError());

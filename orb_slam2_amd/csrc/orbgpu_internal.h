@@ -14,7 +14,7 @@ constexpr int kMinBorder = 16;   // EDGE_THRESHOLD - 3: origin of the FAST searc
 constexpr int kMaxRoots = 128;   // initial quadtree nodes (round(width/height)): the widest strip of the smallest level
 constexpr int kScratchPerNode = 6;  // int32 words of quadtree scratch per entry of a level's two node lists (see octree_level)
 constexpr int kMaxTile = 66;     // largest FAST cell incl. 3 px apron (cells are < 60 px)
-constexpr int kRW = 128, kRH = 32;  // output tile of one resize workgroup
+constexpr int kRW = 128, kRH = 32;  // output tile of one resize workgroup: a wave makes 8 rows, kRH / 8 waves per workgroup (one wave per workgroup, kRH = 8, measured equal)
 
 // Fused pyramid (k_pyr_fused): tile of the last level owned by a workgroup, and what the host tabulates for it: for
 // every tile and level the region {x0, y0, x1, y1} (inclusive) of the level that the tile depends on.
