@@ -1308,6 +1308,29 @@ __device__ __forceinline__ void blur_rows(const uint8_t *__restrict__ in, const 
     const int xlim = (g.w + 15) & ~3, ylim = g.h + 2;
     constexpr int CG = kBW / 4;  // column groups of a tile row
     const bool left_edge = tx0 == 0, right_edge = g.w < tx0 + kBW + 4;  // uniform
+    if (!EDGE && ty0 + kBH + 2 <= ylim) {
+        // an inner tile above the level's last rows: no coordinate is clamped, so a lane's source address advances by a
+        // constant from one of its row pairs to the next and the three dwords of a row are immediate offsets of one
+        // pointer (the loop below derives and clamps every coordinate anew: half of its instructions)
+        static_assert(kBlurThreads % CG == 0, "a lane keeps its column group");
+        constexpr int kStep = kBlurThreads / CG;  // row pairs between a lane's tasks
+        const int c = tid % CG;
+        const uint8_t *r0 = in + (int64_t)(ty0 + 2 * (tid / CG) - 3) * g.pitch + (tx0 - 4 + 4 * c);
+        const int64_t step = (int64_t)(2 * kStep) * g.pitch;
+        uint32_t *dst = hpair + (tid / CG) * kBW + 4 * c;
+        for (int rp = tid / CG; rp < (kBH + 6) / 2; rp += kStep, r0 += step, dst += kStep * kBW) {
+            const uint8_t *r1 = r0 + g.pitch;
+            const uint32_t a0 = *reinterpret_cast<const uint32_t *>(r0), b0 = *reinterpret_cast<const uint32_t *>(r0 + 4),
+                           d0 = *reinterpret_cast<const uint32_t *>(r0 + 8);
+            const uint32_t a1 = *reinterpret_cast<const uint32_t *>(r1), b1 = *reinterpret_cast<const uint32_t *>(r1 + 4),
+                           d1 = *reinterpret_cast<const uint32_t *>(r1 + 8);
+            uint32_t e[4], o[4];
+            blur_row4(a0, b0, d0, klo, khi, e);
+            blur_row4(a1, b1, d1, klo, khi, o);
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(e[0] | (o[0] << 16), e[1] | (o[1] << 16), e[2] | (o[2] << 16), e[3] | (o[3] << 16));
+        }
+        return;
+    }
     for (int i = tid; i < (kBH + 6) / 2 * CG; i += kBlurThreads) {
         const int rp = i / CG, c = i % CG;
         const int y0 = min(ty0 + 2 * rp - 3, ylim), y1 = min(ty0 + 2 * rp - 2, ylim);
