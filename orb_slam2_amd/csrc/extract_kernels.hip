@@ -480,7 +480,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     uint8_t *score = tile + lds_score_off;
     uint32_t *maxima = reinterpret_cast<uint32_t *>(tile);  // strict 3x3 maxima are never adjacent: at most a quarter of the pixels
     uint16_t *queue = reinterpret_cast<uint16_t *>(tile + lds_queue_off);
-    __shared__ int qn, nmax, nini;
+    __shared__ int qn, gqn, nmax, nini;
+    uint32_t *gqueue = reinterpret_cast<uint32_t *>(score);  // the group queue lives where the score plane is cleared afterwards
 #ifdef ORBGPU_STAMPS
     unsigned long long stamp_prev = __builtin_readcyclecounter();
     const unsigned stamp_wg = blockIdx.y * gridDim.x + blockIdx.x;
@@ -509,8 +510,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
         }
         const int wi = cu.cw - 6, hi = cu.ch - 6;
     fast_stage_cell<kTP>(cu, cur, wave, lane, kFastThreads / 64);
-    for (int i = tid; i < ((hi + 2) * SP + 15) >> 4; i += kFastThreads) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) { qn = 0; nmax = 0; nini = 0; }
+    if (tid == 0) { qn = 0; gqn = 0; nmax = 0; nini = 0; }
     fast_stage_wait();
     __syncthreads();
     ORB_STAMP(1);
@@ -527,16 +527,19 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
     const int mdiv = cu.mdiv;
     const uint8_t *t0 = cur + 1;  // pixel (x, y) of the cell image is t0[y * kTP + x]
     const uint32_t *tile32 = reinterpret_cast<const uint32_t *>(cur);
-    const int ngx = (wi + 3) >> 2, ngroups = ngx * hi;  // groups of four interior pixels = dwords 1 .. ngx of a tile row
-    const int mdivg = cu.mdivg;
+    const int ngx = (wi + 3) >> 2;  // groups of four interior pixels = dwords 1 .. ngx of a tile row
     {
         const uint32_t tg = ((uint32_t)t * 0x10001u) | 0x80008000u;  // the threshold under a guard bit in both halves
         constexpr int RP = kTP / 4;
         constexpr uint32_t kSel13 = 0x0c030c01u, kSel24 = 0x0c040c02u, kSel35 = 0x0c050c03u, kSel46 = 0x0c060c04u;
-        for (int i = tid; i < ngroups; i += kFastThreads) {
-            const int y = div_small(i, mdivg), gx = i - (int)__umul24(y, ngx);
+        // thread -> (row, group of the row) once per cell; an iteration of the workgroup covers rows_it whole rows, so
+        // the loop only adds constants (threads past rows_it * ngx idle: at most ngx - 1 of them)
+        const int rows_it = div_small(kFastThreads, cu.mdivg);
+        const int ty = div_small(tid, cu.mdivg), gx = tid - (int)__umul24(ty, ngx);
+        const uint32_t *r = tile32 + ty * RP + gx;
+        uint32_t yg = ((uint32_t)ty << 4) | (uint32_t)gx;
+        for (int y = ty < rows_it ? ty : hi; y < hi; y += rows_it, r += rows_it * RP, yg += (uint32_t)rows_it << 4) {
             // rows y .. y+6 of the tile, three dwords each; the group's pixels are the bytes of the middle dword of row y+3
-            const uint32_t *r = tile32 + y * RP + gx;
             const uint32_t P8 = r[1], Am = r[RP], A0 = r[RP + 1], A1 = r[RP + 2];
             const uint32_t Cm = r[3 * RP], C0 = r[3 * RP + 1], C1 = r[3 * RP + 2];
             const uint32_t Bm = r[5 * RP], B0 = r[5 * RP + 1], B1 = r[5 * RP + 2], P0 = r[6 * RP + 1];
@@ -569,35 +572,59 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
                 const uint32_t r1 = __builtin_bit_cast(uint32_t, dmax) + tg - vi, r2 = vi + tg - __builtin_bit_cast(uint32_t, bmin);
                 verdict[odd] = ~(r1 & r2);
             }
-            const uint32_t S = (verdict[0] & 0x80008000u) | ((verdict[1] & 0x80008000u) >> 1);
-            // bits 15 / 14 / 31 / 30 of S = pixels 0 / 1 / 2 / 3; pixels beyond the interior's last column were tested
-            // on whatever lies there and are dropped.  Survivors are appended to the pixel queue with one LDS atomic
-            // per wave: positions from ballots (the queue's order does not matter, emission ranks by pixel index).
-            const int x0 = gx << 2, left = wi - x0;
-            const int pix0 = (int)__umul24(y, wi) + x0;
-            const bool s0 = (S & 0x8000u) != 0, s1 = (S & 0x4000u) != 0 && left > 1, s2 = (S & 0x80000000u) != 0 && left > 2,
-                       s3 = (S & 0x40000000u) != 0 && left > 3;
-            const uint64_t m0 = __ballot(s0), m1 = __ballot(s1), m2 = __ballot(s2), m3 = __ballot(s3);
-            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-            if (n0 + n1 + n2 + n3) {  // wave-uniform
+            // bits 15 / 14 / 31 / 30 of the entry = pixels 0 / 1 / 2 / 3.  Groups with a survivor go to the group queue as
+            // verdict bits | row << 4 | group: one ballot and one LDS atomic per wave (no order is needed: emission
+            // ranks by pixel index).  Pixels beyond the interior's last column were tested on whatever lies there;
+            // the expansion below drops them.
+            const bool any = ((verdict[0] | verdict[1]) & 0x80008000u) != 0;
+            const uint64_t m = __ballot(any);
+            if (m) {  // wave-uniform
                 int base = 0;
                 const uint64_t act = __ballot(true);
-                if (lane_id() == __ffsll((long long)act) - 1) base = atomicAdd(&qn, n0 + n1 + n2 + n3);
+                if (lane_id() == __ffsll((long long)act) - 1) base = atomicAdd(&gqn, __popcll(m));
                 base = __builtin_amdgcn_readfirstlane(base);
-#define ORB_RANK(m_) (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m_) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m_), 0u))
-                // entries past the queue's capacity are dropped: the cell is then evaluated densely (below)
-                const int q0 = base + ORB_RANK(m0), q1 = base + n0 + ORB_RANK(m1), q2 = base + n0 + n1 + ORB_RANK(m2),
-                          q3 = base + n0 + n1 + n2 + ORB_RANK(m3);
-                if (s0 && q0 < qcap) queue[q0] = (uint16_t)pix0;
-                if (s1 && q1 < qcap) queue[q1] = (uint16_t)(pix0 + 1);
-                if (s2 && q2 < qcap) queue[q2] = (uint16_t)(pix0 + 2);
-                if (s3 && q3 < qcap) queue[q3] = (uint16_t)(pix0 + 3);
-#undef ORB_RANK
+                if (any)
+                    gqueue[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                        (verdict[0] & 0x80008000u) | ((verdict[1] & 0x80008000u) >> 1) | yg;
             }
         }
     }
     __syncthreads();
     ORB_STAMP(2);
+    // the surviving pixels of the queued groups, densely into the pixel queue: a lane per group, positions from a
+    // wave scan of the survivor counts (a wave takes chunks of 64 groups, all its lanes run: the scan needs them);
+    // entries past the pixel queue's capacity are dropped: the cell is then evaluated densely (below)
+    {
+        const int ng = gqn;
+        for (int g0 = wave << 6; g0 < ng; g0 += kFastThreads) {
+            const int g = g0 + lane;
+            const uint32_t e = g < ng ? gqueue[g] : 0u;
+            const int y = (e >> 4) & 63, x0 = (e & 15) << 2, left = wi - x0;
+            const int pix0 = (int)__umul24(y, wi) + x0;
+            const bool s0 = (e & 0x8000u) != 0, s1 = (e & 0x4000u) != 0 && left > 1, s2 = (e & 0x80000000u) != 0 && left > 2,
+                       s3 = (e & 0x40000000u) != 0 && left > 3;
+            const int cnt = (int)s0 + (int)s1 + (int)s2 + (int)s3;
+            const int incl = wave_scan_incl(cnt);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total) {  // wave-uniform
+                int base = 0;
+                if (lane_id() == 0) base = atomicAdd(&qn, total);
+                int pos = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+                if (s0 && pos < qcap) queue[pos] = (uint16_t)pix0;
+                pos += (int)s0;
+                if (s1 && pos < qcap) queue[pos] = (uint16_t)(pix0 + 1);
+                pos += (int)s1;
+                if (s2 && pos < qcap) queue[pos] = (uint16_t)(pix0 + 2);
+                pos += (int)s2;
+                if (s3 && pos < qcap) queue[pos] = (uint16_t)(pix0 + 3);
+            }
+        }
+    }
+    __syncthreads();
+    // the score plane (interior + 1 px border) starts from zero; it takes the group queue's place
+    for (int i = tid; i < ((hi + 2) * SP + 15) >> 4; i += kFastThreads) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    ORB_STAMP(3);
     // The queue holds qcap entries, which keeps the workgroup's LDS small enough for a CU to hold 32 of them; a cell
     // with more survivors (noise at a low threshold) is evaluated densely instead, every pixel of it: the arc score
     // decides alone, so the result is the same.
@@ -1787,7 +1814,9 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
     const int kTP = wmax + 6 + 4 <= kTPNarrow ? kTPNarrow : kTPWide;
     const int tile_bytes = ((hmax + 6) * kTP + 255) & ~255;  // whole 64-dword pieces of the direct global -> LDS copy
     const int score_pitch = (wmax + 2 + 3) & ~3, score_off = tile_bytes;
-    const int queue_off = score_off + (((hmax + 2) * score_pitch + 15) & ~15);
+    // the region of the score plane first holds the group queue (a word per group of four interior pixels)
+    const int score_bytes = ((hmax + 2) * score_pitch + 15) & ~15, gqueue_bytes = ((wmax + 3) / 4 * hmax * 4 + 15) & ~15;
+    const int queue_off = score_off + (score_bytes > gqueue_bytes ? score_bytes : gqueue_bytes);
     // the survivor queue: all pixels of the largest cell if that keeps the workgroup within a 32nd of a CU's LDS (5120
     // bytes, 16 of them static), else what is left of that share but at least 256 entries
     constexpr int kLdsShare = 160 * 1024 / 32 - 16;
