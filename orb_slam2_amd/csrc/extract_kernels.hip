@@ -438,26 +438,27 @@ __device__ __forceinline__ FastCell fast_cell_info(const uint8_t *__restrict__ p
 typedef __attribute__((address_space(3))) void fast_lvoid;
 
 // Copy a cell image into a tile buffer (rows of kTP bytes) with direct global -> LDS loads: no registers, and the
-// copy proceeds while the wave computes.  One wave instruction writes 64 consecutive dwords of the buffer, so lane
-// L of piece p owns dword 64 p + L = (row, column) of the tile; rows and columns past the cell re-read its last
-// row / dword (the buffer is padded to whole pieces).  The loads are issued from an asm statement: issued through
-// the builtin, the compiler orders every later LDS write and atomic of the wave behind them (it cannot see that
-// they go to the other buffer), which would stall the wave until the copy has landed.  The caller therefore
-// waits itself (fast_stage_wait) before the barrier that precedes the first read of the buffer.
+// copy proceeds while the wave computes.  Rows and columns past the cell re-read its last row / dword (the buffer
+// is padded for the last piece).  The loads are issued from an asm statement: issued through the builtin, the
+// compiler orders every later LDS write and atomic of the wave behind them, which would stall the wave until the
+// copy has landed.  The caller therefore waits itself (fast_stage_wait) before the barrier that precedes the first
+// read of the buffer.
 template <int kTP>
 __device__ __forceinline__ void fast_stage_cell(const FastCell &c, uint8_t *buf, int wave, int lane, int nwaves)
 {
-    constexpr int RP = kTP / 4;
-    constexpr int kRecip = (65536 + RP - 1) / RP;  // d / RP = d * kRecip >> 16 for the d < 2^13 of a tile
-    const int npieces = (c.ch * RP + 63) >> 6;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(fast_lvoid *)buf;
+    // A piece = one wave instruction = 64 consecutive dwords of the buffer.  Pieces start on whole tile rows, kRPP
+    // rows apart: a lane's (row within the piece, column) is then the same for every piece, and a piece costs three
+    // vector instructions.  The lanes past the piece's kRPP rows load the first dwords of the next piece's first
+    // row, exactly what that piece's first lanes write there, so the two writers of those dwords agree.
+    constexpr int RP = kTP / 4, kRPP = 64 / RP;
+    const int lr = lane / RP, lc = lane - lr * RP;
+    const uint32_t coloff = 4u * (uint32_t)min(lc, c.ndw - 1);
+    const int npieces = (c.ch + kRPP - 1) / kRPP;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fast_lvoid *)buf);
     const uint8_t *src = c.src;  // uniform: the loads take it as their scalar base and a 32-bit lane offset
     for (int p = wave; p < npieces; p += nwaves) {
-        const int d = (p << 6) + lane;
-        const int row = (d * kRecip) >> 16;
-        const int col = d - row * RP;
-        const uint32_t off = (uint32_t)min(row, c.ch - 1) * (uint32_t)c.pitch + 4u * (uint32_t)min(col, c.ndw - 1);
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + ((uint32_t)p << 8));
+        const uint32_t off = (uint32_t)min(kRPP * p + lr, c.ch - 1) * (uint32_t)c.pitch + coloff;
+        const uint32_t dst = lds0 + (uint32_t)p * (uint32_t)(kRPP * kTP);
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
@@ -1812,7 +1813,9 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
     }
     // a tile row holds the cell image (cell + 6) behind one lead byte, in whole dwords
     const int kTP = wmax + 6 + 4 <= kTPNarrow ? kTPNarrow : kTPWide;
-    const int tile_bytes = ((hmax + 6) * kTP + 255) & ~255;  // whole 64-dword pieces of the direct global -> LDS copy
+    // the direct global -> LDS copy writes 64 dwords per piece, a piece every 64 / (kTP / 4) rows: the last one runs
+    // past the tile's last row
+    const int rpp = 64 / (kTP / 4), tile_bytes = ((((hmax + 6 + rpp - 1) / rpp - 1) * rpp * kTP + 256) + 15) & ~15;
     const int score_pitch = (wmax + 2 + 3) & ~3, score_off = tile_bytes;
     // the region of the score plane first holds the group queue (a word per group of four interior pixels)
     const int score_bytes = ((hmax + 2) * score_pitch + 15) & ~15, gqueue_bytes = ((wmax + 3) / 4 * hmax * 4 + 15) & ~15;
