@@ -1700,13 +1700,22 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     const uint8_t *pb = patch[wv];
     uint32_t pre[6];
     // dword m of keypoint j's patch: columns (x - 18 rounded down to 4) + 4 scol .., row y - 18 + srow, in the tiled plane
+    // blur_tiled_off(pitch, xb + 4 scol, yb + srow) with its uniform parts on the scalar side: the first column is a
+    // multiple of 4, so the address is ((y >> 5) * (pitch >> 2) << 7) + ((y & 31) << 2) + a lane constant + a scalar
+    int scol7[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) scol7[m] = scol[m] << 7;
     auto patch_loads = [&](int j, uint32_t (&dst)[6]) {
         const int pitch = __builtin_amdgcn_readlane(my_pitch, j), kx = __builtin_amdgcn_readlane(my_x, j);
         const int ky = __builtin_amdgcn_readlane(my_y, j);
-        const uint8_t *c = fblur + __builtin_amdgcn_readlane(my_plane, j);
         const int xb = (kx - kBR) & ~3, yb = ky - kBR;
+        const uint8_t *c = fblur + __builtin_amdgcn_readlane(my_plane, j) + (((xb + kLeftMargin) >> 2) << 7);  // uniform
+        const int k128 = (pitch >> 2) << 7;
 #pragma unroll
-        for (int m = 0; m < 6; m++) dst[m] = *reinterpret_cast<const uint32_t *>(c + blur_tiled_off(pitch, xb + 4 * scol[m], yb + srow[m]));
+        for (int m = 0; m < 6; m++) {
+            const int y = yb + srow[m];
+            dst[m] = *reinterpret_cast<const uint32_t *>(c + (uint32_t)((y >> 5) * k128 + ((y & 31) << 2) + scol7[m]));
+        }
     };
     patch_loads(0, pre);
     // the pattern as floats, once per wave
