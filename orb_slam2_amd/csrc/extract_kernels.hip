@@ -1275,10 +1275,11 @@ __global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
         octree_level<false>(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
                             dyn_coff_off, pts_cap, dyn_pts_off);
 }
-// a batch: 256-thread workgroups, registers capped so that eight of them share a CU.  The grid is (frames, levels):
+// a batch: 128-thread workgroups (LDS lets nine of them share a CU: five waves per SIMD, hence the register budget;
+// 256 threads with registers capped at 64 measured 7 % slower, 64 threads 20 %).  The grid is (frames, levels):
 // workgroups start in linear order, so the levels with the most candidates (the lowest) start first and the short
 // ones fill the tail.
-__global__ __launch_bounds__(256, 8) void k_octree_batch(OCTREE_ARGS)
+__global__ __launch_bounds__(128, 5) void k_octree_batch(OCTREE_ARGS)
 {
     if (lds_nodes)
         octree_level<true>(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
@@ -1871,8 +1872,9 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     if (keys_cap > 4096) keys_cap = 0;         // no room in LDS: the keys go to the level's global scratch
     const size_t node_bytes = (size_t)maxcap * (2 * sizeof(QNode) + 8 * sizeof(int32_t));
     const int lds_nodes = keys_cap && (size_t)keys_cap * 8 + node_bytes <= 56 * 1024;
-    // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several
-    const int threads = nimg * G.nlevels >= 256 ? 256 : 1024;
+    // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several (two waves each:
+    // fewer waves wait at every barrier of the subdivision rounds)
+    const int threads = nimg * G.nlevels >= 256 ? 128 : 1024;
     const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
     size_t dyn = coff_off + (size_t)(threads + 1) * 4;
     if (nimg * G.nlevels >= 256) {
