@@ -1536,23 +1536,25 @@ constexpr int kDescGroup = 8;   // keypoint slots per wave
 constexpr int kBR = 18;         // largest rotated pattern coordinate: round(hypot(13, 13))
 constexpr int kBPitch = 40;     // bytes per staged row of the blurred patch: 37 + up to 3 of alignment
 
-__global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, Geom G,
+__global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, Geom G,
                                                   const uint32_t *__restrict__ sel, const int32_t *__restrict__ sel_count,
                                                   const int8_t *__restrict__ pattern, orbgpu_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int capacity,
                                                   int32_t *__restrict__ status)
 {
+    // One wave per workgroup (waves never cooperate here; four-wave workgroups take the same time alone but pack
+    // worse beside the other streams' kernels: 303 k against 309 k frames/s for the whole step).
     // A wave owns kDescGroup consecutive keypoint slots.  Stage A: intensity
     // centroid of each (aligned 32-bit loads, dot products against per-lane
     // weights).  Stage B: lane j turns the moments of keypoint j into angle,
     // sine and cosine -- once for the whole group.  Stage C: the blurred patch
     // of each keypoint goes through LDS and the 256 tests read it from there.
-    __shared__ __align__(16) uint8_t patch[4][(2 * kBR + 1) * kBPitch];
+    __shared__ __align__(16) uint8_t patch[1][(2 * kBR + 1) * kBPitch];
     int f, blk;
     if (!frame_block(G.nimg, &f, &blk)) return;
     const int lane = lane_id();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot0 = (blk * 4 + wv) * kDescGroup;
+    const int slot0 = (blk * 1 + wv) * kDescGroup;
     if (slot0 >= G.total_kp_cap) return;
     const int32_t *sc = sel_count + f * G.nlevels;
 #ifdef ORBGPU_STAMPS
@@ -1932,7 +1934,7 @@ int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t 
 {
     Geom G = G_;
     G.nimg = nimg;
-    hipLaunchKernelGGL(k_describe, frame_grid((G.total_kp_cap + 4 * kDescGroup - 1) / (4 * kDescGroup), nimg), dim3(256), 0, st, pyr,
+    hipLaunchKernelGGL(k_describe, frame_grid((G.total_kp_cap + 1 * kDescGroup - 1) / (1 * kDescGroup), nimg), dim3(64), 0, st, pyr,
                        blur, G, sel, sel_count,
                        pattern, kps, desc, counts, capacity, status);
     ORBGPU_HIP_CHECK(hipGetLastError());
