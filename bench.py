@@ -411,8 +411,8 @@ def run_tum(args, rank, local_rank, world, torch, dev, barrier):
                   "launch_ms": float(stage_ms[dom]), "launch_ms_isolated": float(iso_ms[dom]),
                   "achieved_isolated": dom_bytes / (float(iso_ms[dom]) * 1e-3) / 1e9, "valu_issue": valu,
                   "source": {"achieved": "HIP events in this run", "traffic_and_instruction_counts": src + ["builder-run rocprofv3 --pmc passes"]},
-                  "note": "integer byte kernel: its HBM traffic is at the algorithmic volume, the time goes into vector instructions "
-                          "(valu_issue: instructions per launch over the isolated launch time, against the measured issue rate)"},
+                  "note": "integer byte kernel: its L2 fetches stay within about twice the algorithmic volume, the time goes into vector "
+                          "instructions (valu_issue: instructions per launch over the isolated launch time, against the measured issue rate)"},
         stages_ms_per_step={n: float(v) for n, v in zip(names, stage_ms)},
         stages_ms_isolated={n: float(v) for n, v in zip(names, iso_ms)},
         extract_algorithmic_GBps=frame_alg * Bs / (float(iso_ms.sum()) * 1e-3) / 1e9,
