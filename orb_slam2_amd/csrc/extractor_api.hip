@@ -835,7 +835,7 @@ static int extract_batch_chunked(orbgpu_extractor *e, const uint8_t *const *imgs
 {
     const int cap = e->G.total_kp_cap;
     const size_t fbytes = (size_t)w * h;
-    int chunk = std::max(kChunkMin / 2, (nimg + 7) / 8);
+    int chunk = std::max(kChunkMin / 2, (nimg + 5) / 6);
     const int nchunks = (nimg + chunk - 1) / chunk;
     if (!e->up_stream) {
         ORBGPU_HIP_CHECK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
