@@ -528,7 +528,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2048, help="tum: frames per step and GPU")
     ap.add_argument("--streams", type=int, default=4, help="tum: independent sub-pipelines (HIP streams) the batch is split over")
     ap.add_argument("--frames-4k", type=int, default=256, help="4k: frames of the whole job per step")
-    ap.add_argument("--launch-4k", type=int, default=64, help="4k: frames per launch")
+    ap.add_argument("--launch-4k", type=int, default=256, help="4k: frames per launch (at most the rank's share)")
     ap.add_argument("--no-latency", action="store_true", help="skip the host-side latency / PCIe probes (profiling runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     args = ap.parse_args()

@@ -1275,11 +1275,15 @@ __global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
         octree_level<false>(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
                             dyn_coff_off, pts_cap, dyn_pts_off);
 }
-// a batch: 128-thread workgroups (LDS lets nine of them share a CU: five waves per SIMD, hence the register budget;
-// 256 threads with registers capped at 64 measured 7 % slower, 64 threads 20 %).  The grid is (frames, levels):
-// workgroups start in linear order, so the levels with the most candidates (the lowest) start first and the short
-// ones fill the tail.
-__global__ __launch_bounds__(128, 5) void k_octree_batch(OCTREE_ARGS)
+// a batch: small workgroups, many per CU.  The grid is (frames, levels): workgroups start in linear order, so the
+// levels with the most candidates (the lowest) start first and the short ones fill the tail.  The size follows the
+// work of a level: 128 threads (LDS lets nine share a CU: five waves per SIMD, hence the register budget) for
+// levels of a few hundred features -- fewer waves then wait at every barrier of the subdivision rounds (TUM frames:
+// 256 threads with registers capped at 64 measured 7 % slower, 64 threads 20 %); for levels of thousands of features
+// (3840 x 2160, 8000 features: 20 000 candidates on level 0) 256 threads when the launch has 2048 workgroups or
+// more, else 512 (64 such frames: 1.30 / 0.81 / 0.49 ms with 128 / 256 / 512 threads).
+template <int kThreads, int kWavesPerSimd>
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_octree_batch(OCTREE_ARGS)
 {
     if (lds_nodes)
         octree_level<true>(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
@@ -1874,14 +1878,24 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     if (keys_cap > 4096) keys_cap = 0;         // no room in LDS: the keys go to the level's global scratch
     const size_t node_bytes = (size_t)maxcap * (2 * sizeof(QNode) + 8 * sizeof(int32_t));
     const int lds_nodes = keys_cap && (size_t)keys_cap * 8 + node_bytes <= 56 * 1024;
-    // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several (two waves each:
-    // fewer waves wait at every barrier of the subdivision rounds)
-    const int threads = nimg * G.nlevels >= 256 ? 128 : 1024;
+    // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several
+    const bool batch = nimg * G.nlevels >= 256;
+    int threads = !batch ? 1024 : maxcap <= 512 ? 128 : nimg * G.nlevels >= 2048 ? 256 : 512;
+    if (batch) {  // measurement hook
+        if (const char *ov = getenv("ORBGPU_OCT_THREADS")) threads = atoi(ov) == 128 ? 128 : atoi(ov) == 512 ? 512 : 256;
+    }
     const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
     size_t dyn = coff_off + (size_t)(threads + 1) * 4;
-    if (nimg * G.nlevels >= 256) {
-        hipLaunchKernelGGL(k_octree_batch, dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch,
-                           sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, 0, 0);
+    if (batch) {
+        if (threads == 128)
+            hipLaunchKernelGGL((k_octree_batch<128, 5>), dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes,
+                               scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, 0, 0);
+        else if (threads == 256)
+            hipLaunchKernelGGL((k_octree_batch<256, 8>), dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes,
+                               scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, 0, 0);
+        else
+            hipLaunchKernelGGL((k_octree_batch<512, 4>), dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes,
+                               scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, 0, 0);
     } else {
         // the two candidate buffers of a level in LDS too, as far as 144 KiB go (a workgroup may use the whole CU's)
         const size_t pts_off = (dyn + 15) & ~(size_t)15, budget = 144 * 1024;
