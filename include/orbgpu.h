@@ -210,6 +210,14 @@ int orbgpu_hamming_bruteforce_device(orbgpu_matcher *m, const uint8_t *d_Q, int3
                                      const uint8_t *d_T, int32_t nt, int32_t *d_best_idx,
                                      int32_t *d_best_d, int32_t *d_second_d);
 
+/* Which kernel the brute-force scan of this handle runs on (no counterpart in the
+ * reference; results are identical): 0 = chosen by size (the default), 1 = the
+ * vector-unit kernel (xor + population count per pair), 2 = the matrix-core kernel
+ * (descriptors spread to one byte per bit, v_mfma_i32_32x32x32_i8; distances follow
+ * from |a| + |b| - 2 * popcount(a & b)).  The allocation-free entry point below always
+ * runs the vector-unit kernel. */
+int orbgpu_matcher_set_bruteforce_kernel(orbgpu_matcher *m, int32_t which);
+
 /* orbgpu_hamming_bruteforce_device for callers that cannot allocate (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
  * no counterpart in the reference.  Same arguments, same results; it calls no

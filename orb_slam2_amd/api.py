@@ -37,7 +37,7 @@ EXPORTS = [
     "orbgpu_debug_level_candidates", "orbgpu_debug_level_selected",
     "orbgpu_matcher_create", "orbgpu_matcher_destroy", "orbgpu_matcher_set_stream", "orbgpu_matcher_sync", "orbgpu_matcher_set_grid_geometry",
     "orbgpu_descriptor_distance", "orbgpu_hamming_bruteforce", "orbgpu_hamming_bruteforce_device",
-    "orbgpu_hamming_bruteforce_device_noalloc",
+    "orbgpu_hamming_bruteforce_device_noalloc", "orbgpu_matcher_set_bruteforce_kernel",
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
     "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_in_area", "orbgpu_assign_features_to_grid",
     "orbgpu_distinctive_descriptors", "orbgpu_stereo_from_rgbd", "orbgpu_undistort_keypoints", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
@@ -105,6 +105,7 @@ def load_library():
         L.orbgpu_hamming_bruteforce.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
         L.orbgpu_hamming_bruteforce_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
         L.orbgpu_hamming_bruteforce_device_noalloc.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+        L.orbgpu_matcher_set_bruteforce_kernel.argtypes = [vp, i32]
         L.orbgpu_search_by_projection.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                   C.POINTER(i32)]
         L.orbgpu_search_by_projection_batch_device.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp,
@@ -510,6 +511,10 @@ class ORBmatcher:
         """Grid geometry of the next windowed search only: (build origin x, y, query origin x, y, 1/cell w, 1/cell h)."""
         g = None if geom6 is None else np.ascontiguousarray(geom6, np.float32)
         _check(self._lib.orbgpu_matcher_set_grid_geometry(self._h, _p(g)), "orbgpu_matcher_set_grid_geometry")
+
+    def set_bruteforce_kernel(self, which):
+        """0: by size, 1: vector-unit kernel, 2: matrix-core kernel (same results)."""
+        _check(self._lib.orbgpu_matcher_set_bruteforce_kernel(self._h, int(which)), "orbgpu_matcher_set_bruteforce_kernel")
 
     @staticmethod
     def DescriptorDistance(a, b):

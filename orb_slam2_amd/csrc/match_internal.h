@@ -69,6 +69,17 @@ __device__ __forceinline__ int hamming8(const uint32_t (&a)[8], const uint32_t *
 }
 #endif
 
+// Matrix-core brute force (bf_mfma_kernels.hip): sizes of one call -- query tiles of 32 per wave, padded counts, the
+// chunking of the train set and the layout of the workspace (byte-per-bit images, accumulator constants, partial results).
+struct BfMfmaPlan {
+    int nq_tile;
+    int nq_pad, nt_pad, ntiles, tiles_per_chunk, nchunks, chunk;
+    size_t off_qx, off_tx, off_cinit, off_part, bytes;
+};
+BfMfmaPlan bf_mfma_plan(int nq, int nt);
+int launch_bruteforce_mfma(hipStream_t st, const BfMfmaPlan &P, const uint8_t *d_Q, int nq, const uint8_t *d_T, int nt, uint8_t *ws,
+                           int32_t *bi, int32_t *b1, int32_t *b2);
+
 // Frame::ComputeStereoMatches inputs (src/Frame.cc:600-774).
 struct StereoArgs {
     const orbgpu_keypoint *kpsL; const uint8_t *descL; int32_t nL;

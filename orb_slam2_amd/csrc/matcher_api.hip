@@ -96,6 +96,8 @@ struct orbgpu_matcher {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     MBuf part;     // brute-force partial results
+    MBuf bfws;     // matrix-core brute force: byte-per-bit images of both descriptor sets and the chunks' partial results
+    int bf_kernel = 0;  // 0: chosen by size, 1: vector-unit kernel, 2: matrix-core kernel (orbgpu_matcher_set_bruteforce_kernel)
     MBuf scratch;  // window matcher scratch
     MBuf stats;    // resolver statistics of the last window call
     int stats_pairs = 0;
@@ -129,6 +131,8 @@ static void grid_geometry(orbgpu_matcher *m, const float *b4, MatchArgs *A)
         A->invH = (float)ORBGPU_GRID_ROWS / (b4[3] - b4[1]);
     }
 }
+
+static const int64_t kBfMfmaMinPairs = 4 << 20;
 
 static void choose_split(int nq, int nt, int *nsplit, int *tchunk)
 {
@@ -198,6 +202,7 @@ void orbgpu_matcher_destroy(orbgpu_matcher *m)
         m->stream = m->own_stream;  // a caller's stream does not outlive its use of the handle
         m->geom_set = false;
         m->stats_pairs = 0;
+        m->bf_kernel = 0;
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         if (g_pool[m->device].size() < kPoolPerDevice) {
             g_pool[m->device].push_back(m);
@@ -205,6 +210,7 @@ void orbgpu_matcher_destroy(orbgpu_matcher *m)
         }
     }
     m->part.release();
+    m->bfws.release();
     m->scratch.release();
     m->stats.release();
     for (auto &b : m->stage) b.release();
@@ -264,11 +270,29 @@ int orbgpu_hamming_bruteforce_device(orbgpu_matcher *m, const uint8_t *d_Q, int3
     }
     if (nq == 0) return ORBGPU_OK;
     ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    // the matrix-core kernel pays for spreading both sets to a byte per bit: worth it from a few million pairs on
+    const bool mfma = nt > 0 && (m->bf_kernel == 2 || (m->bf_kernel == 0 && (int64_t)nq * nt >= kBfMfmaMinPairs));
+    if (mfma) {
+        const BfMfmaPlan P = bf_mfma_plan(nq, nt);
+        int rc = m->bfws.ensure(P.bytes);
+        if (rc) return rc;
+        return launch_bruteforce_mfma(m->stream, P, d_Q, nq, d_T, nt, (uint8_t *)m->bfws.p, d_best_idx, d_best_d, d_second_d);
+    }
     int nsplit, tchunk;
     choose_split(nq, nt, &nsplit, &tchunk);
     int rc = m->part.ensure((size_t)nsplit * nq * sizeof(uint2));
     if (rc) return rc;
     return launch_bruteforce(m->stream, d_Q, nq, d_T, nt, nsplit, tchunk, (uint2 *)m->part.p, d_best_idx, d_best_d, d_second_d);
+}
+
+int orbgpu_matcher_set_bruteforce_kernel(orbgpu_matcher *m, int32_t which)
+{
+    if (!m || which < 0 || which > 2) {
+        set_error("orbgpu_matcher_set_bruteforce_kernel: which must be 0 (by size), 1 (vector unit) or 2 (matrix cores)");
+        return ORBGPU_E_INVALID;
+    }
+    m->bf_kernel = which;
+    return ORBGPU_OK;
 }
 
 // Same scan without any allocation: the per-chunk partial results go to this device's fixed

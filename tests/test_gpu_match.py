@@ -34,17 +34,42 @@ def test_descriptor_distance_kats(oracle):
         assert ORBmatcher.DescriptorDistance(a, b) == ref == oracle.hamming(a, b)
 
 
-@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 300), (257, 1000), (1000, 1003), (3000, 7)])
-def test_bruteforce_small(matcher, oracle, nq, nt):
+@pytest.fixture(params=[0, 1, 2], ids=["by_size", "vector_unit", "matrix_cores"])
+def bf_matcher(request, matcher):
+    """The module's matcher with the brute-force kernel pinned (both kernels must give the scan's results at every size)."""
+    matcher.set_bruteforce_kernel(request.param)
+    yield matcher
+    matcher.set_bruteforce_kernel(0)
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 300), (257, 1000), (1000, 1003), (3000, 7), (300, 8200), (1025, 16400)])
+def test_bruteforce_small(bf_matcher, oracle, nq, nt):
     Q = synth.descriptors(nq, 5); T = synth.descriptors(nt, 6)
     T[nt // 2] = Q[0]  # an exact hit
     if nt > 3:
         T[1] = T[3]    # duplicate train rows: lowest index must win
         Q[nq - 1] = T[3]
-    got = matcher.BruteForce(Q, T)
+    if nt > 8200:      # equal rows on both sides of a chunk boundary of the matrix-core kernel, and in its last tile
+        T[8191] = T[8192] = T[nt - 1] = Q[1]
+    got = bf_matcher.BruteForce(Q, T)
     ref = oracle.bruteforce(Q, T)
     for g, r in zip(got, ref):
         assert np.array_equal(g, r)
+
+
+def test_bruteforce_extreme_descriptors(bf_matcher, oracle):
+    """All-zero and all-one descriptors, near-duplicates and a train set of one value: the largest and smallest
+    distances, and ties everywhere (the lowest index wins, the second distance equals the first)."""
+    rng = np.random.default_rng(11)
+    Q = synth.descriptors(200, 5); T = synth.descriptors(500, 6)
+    Q[0] = 0; Q[1] = 255; T[7] = 0; T[8] = 255; T[9] = 0
+    for k in range(20):  # near-duplicates of query 2: single-bit differences
+        T[20 + k] = Q[2]; T[20 + k, rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+    for QQ, TT in ((Q, T), (Q, np.repeat(T[:1], 300, axis=0)), (np.zeros((3, 32), np.uint8), np.full((70, 32), 255, np.uint8))):
+        got = bf_matcher.BruteForce(QQ, TT)
+        ref = oracle.bruteforce(QQ, TT)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g, r)
 
 
 def test_bruteforce_empty_train(matcher):
@@ -53,10 +78,10 @@ def test_bruteforce_empty_train(matcher):
     assert (bi == -1).all() and (b1 == 256).all() and (b2 == 256).all()
 
 
-def test_bruteforce_planted_20k(matcher, oracle):
+def test_bruteforce_planted_20k(bf_matcher, oracle):
     Q = synth.descriptors(20000, 5)
     T, perm = synth.planted(Q, 6)
-    bi, b1, b2 = matcher.BruteForce(Q, T)
+    bi, b1, b2 = bf_matcher.BruteForce(Q, T)
     inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
     assert (bi == inv).mean() > 0.999          # planted partner found
     sub = np.arange(0, 20000, 97)
@@ -372,6 +397,17 @@ def test_bruteforce_100k_properties(matcher):
         assert b1[i] == ORBmatcher.DescriptorDistance(Q[i], T[bi[i]])
     si, s1, s2 = matcher.BruteForce(Q[:5000], Q[:5000])
     assert np.array_equal(si, np.arange(5000)) and (s1 == 0).all() and (s2 > 0).all()
+    # the two kernels (xor + population count on the vector unit, byte-per-bit products on the matrix cores) must agree
+    # on every one of the 100 000 results, unplanted (uniform random, many near-ties) train set included
+    T2 = synth.descriptors(100000, 6)
+    try:
+        for TT in (T, T2):
+            matcher.set_bruteforce_kernel(1); v = matcher.BruteForce(Q, TT)
+            matcher.set_bruteforce_kernel(2); x = matcher.BruteForce(Q, TT)
+            for a, b in zip(v, x):
+                assert np.array_equal(a, b)
+    finally:
+        matcher.set_bruteforce_kernel(0)
 
 
 @pytest.mark.parametrize("mode,th,tcap", [(1, 15.0, 1100), (0, 9.0, 1100), (2, 30.0, 1100), (1, 40.0, 1500), (0, 20.0, 1400)])
