@@ -32,12 +32,7 @@ constexpr int kBfTileBytes = kBfTile * 256; // byte-per-bit image of a tile
 constexpr int kBfChunkMax = 8192;           // train descriptors per chunk: the key keeps 13 bits for the index
 constexpr int kBfInvalid = -(1 << 30);      // accumulator constant of the rows that pad the last tile
 
-__device__ __forceinline__ int med3_i32(int a, int b, int c)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+__device__ __forceinline__ int med3_i32(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 
 // 16 bits -> 16 bytes of 0x00 / 0x80.  A nibble x times 0x204081 puts bit i of x at bit 8 i (the partial products
 // do not overlap), the mask keeps those, the shift makes them the byte's sign bit.
@@ -78,15 +73,21 @@ __global__ __launch_bounds__(256) void k_bf_expand(const uint8_t *__restrict__ d
     }
 }
 
-template <int NQ>
+#ifndef BF_TB
+#define BF_TB 1
+#endif
+constexpr int kBfStage = BF_TB;  // tiles per LDS stage (one workgroup barrier per stage); the train set is padded to whole stages
+
+template <int NQ, int TB>
 __global__ __launch_bounds__(256) void k_bf_mfma(const uint8_t *__restrict__ Qx, int nq_pad, const uint8_t *__restrict__ Tx,
                                                  const int32_t *__restrict__ cinit, int tiles_per_chunk, int ntiles,
                                                  int2 *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2][kBfTileBytes + 128];
+    constexpr int kStageBytes = TB * kBfTileBytes;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2][kStageBytes + TB * 128];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int q0 = (blockIdx.x * 4 + wave) * (NQ * 32);
-    const int tile0 = blockIdx.y * tiles_per_chunk, tile1 = min(ntiles, tile0 + tiles_per_chunk);
+    const int tile0 = blockIdx.y * tiles_per_chunk, tile1 = min(ntiles, tile0 + tiles_per_chunk);  // multiples of TB
 
     // B operands: lane (r, h) holds bytes h * 128 + s * 16 .. + 15 of query r for step s
     v4i qf[NQ][8];
@@ -100,47 +101,51 @@ __global__ __launch_bounds__(256) void k_bf_mfma(const uint8_t *__restrict__ Qx,
 #pragma unroll
     for (int n = 0; n < NQ; n++) m1[n] = m2[n] = kBfInvalid * 2 + 1;  // below every key
 
-    v4i g0, g1, g2 = {0, 0, 0, 0};
+    v4i g[2 * TB], gc = {0, 0, 0, 0};
     auto fetch = [&](int t) {
         const uint8_t *src = Tx + (size_t)t * kBfTileBytes + tid * 16;
-        g0 = *reinterpret_cast<const v4i *>(src);
-        g1 = *reinterpret_cast<const v4i *>(src + 4096);
-        if (tid < 8) g2 = *reinterpret_cast<const v4i *>(cinit + (size_t)t * kBfTile + tid * 4);
+#pragma unroll
+        for (int k = 0; k < 2 * TB; k++) g[k] = *reinterpret_cast<const v4i *>(src + k * 4096);
+        if (tid < 8 * TB) gc = *reinterpret_cast<const v4i *>(cinit + (size_t)t * kBfTile + tid * 4);
     };
     auto stash = [&](int b) {
-        *reinterpret_cast<v4i *>(&lds[b][tid * 16]) = g0;
-        *reinterpret_cast<v4i *>(&lds[b][4096 + tid * 16]) = g1;
-        if (tid < 8) *reinterpret_cast<v4i *>(&lds[b][kBfTileBytes + tid * 16]) = g2;
+#pragma unroll
+        for (int k = 0; k < 2 * TB; k++) *reinterpret_cast<v4i *>(&lds[b][k * 4096 + tid * 16]) = g[k];
+        if (tid < 8 * TB) *reinterpret_cast<v4i *>(&lds[b][kStageBytes + tid * 16]) = gc;
     };
     if (tile0 < tile1) {
         fetch(tile0);
         stash(0);
     }
     __syncthreads();
-    for (int t = tile0; t < tile1; t++) {
-        const int b = (t - tile0) & 1;
-        const bool more = t + 1 < tile1;
-        if (more) fetch(t + 1);
-        // A operand of step s: piece h * 8 + s of row r
-        v4i a[8];
+    for (int t = tile0; t < tile1; t += TB) {
+        const int b = ((t - tile0) / TB) & 1;
+        const bool more = t + TB < tile1;
+        if (more) fetch(t + TB);
 #pragma unroll
-        for (int s = 0; s < 8; s++) a[s] = *reinterpret_cast<const v4i *>(&lds[b][((r << 4) + ((h * 8 + s) ^ (r & 15))) * 16]);
-        // accumulator constants: register i of a lane is row (i & 3) + 8 * (i >> 2) + 4 * h
-        v16i c;
+        for (int u = 0; u < TB; u++) {
+            const uint8_t *img = &lds[b][u * kBfTileBytes];
+            // A operand of step s: piece h * 8 + s of row r
+            v4i a[8];
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const v4i cc = *reinterpret_cast<const v4i *>(&lds[b][kBfTileBytes + (8 * g + 4 * h) * 4]);
-            c[4 * g + 0] = cc[0]; c[4 * g + 1] = cc[1]; c[4 * g + 2] = cc[2]; c[4 * g + 3] = cc[3];
-        }
+            for (int s = 0; s < 8; s++) a[s] = *reinterpret_cast<const v4i *>(img + ((r << 4) + ((h * 8 + s) ^ (r & 15))) * 16);
+            // accumulator constants: register i of a lane is row (i & 3) + 8 * (i >> 2) + 4 * h
+            v16i c;
 #pragma unroll
-        for (int n = 0; n < NQ; n++) {
-            v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], qf[n][0], c, 0, 0, 0);
+            for (int k = 0; k < 4; k++) {
+                const v4i cc = *reinterpret_cast<const v4i *>(&lds[b][kStageBytes + u * 128 + (8 * k + 4 * h) * 4]);
+                c[4 * k + 0] = cc[0]; c[4 * k + 1] = cc[1]; c[4 * k + 2] = cc[2]; c[4 * k + 3] = cc[3];
+            }
 #pragma unroll
-            for (int s = 1; s < 8; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], qf[n][s], acc, 0, 0, 0);
+            for (int n = 0; n < NQ; n++) {
+                v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], qf[n][0], c, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                m2[n] = med3_i32(m1[n], m2[n], acc[i]);
-                m1[n] = max(m1[n], acc[i]);
+                for (int s = 1; s < 8; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], qf[n][s], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    m2[n] = med3_i32(m1[n], m2[n], acc[i]);
+                    m1[n] = max(m1[n], acc[i]);
+                }
             }
         }
         if (more) stash(b ^ 1);
@@ -188,7 +193,7 @@ BfMfmaPlan bf_mfma_plan(int nq, int nt)
     P.nq_tile = 2;
     const int qb = 4 * P.nq_tile * 32;
     P.nq_pad = (nq + qb - 1) / qb * qb;
-    P.ntiles = (nt + kBfTile - 1) / kBfTile;
+    P.ntiles = ((nt + kBfTile - 1) / kBfTile + kBfStage - 1) / kBfStage * kBfStage;
     P.nt_pad = P.ntiles * kBfTile;
     // enough workgroups to fill 256 CUs several times over, chunks of at most 8192 train descriptors
     const int qblocks = P.nq_pad / qb;
@@ -196,6 +201,7 @@ BfMfmaPlan bf_mfma_plan(int nq, int nt)
     if (want < 1) want = 1;
     int tpc = (P.ntiles + want - 1) / want;
     if (tpc < 4) tpc = 4;  // a workgroup's query fragments are worth at least a few tiles
+    tpc = (tpc + kBfStage - 1) / kBfStage * kBfStage;
     if (tpc > kBfChunkMax / kBfTile) tpc = kBfChunkMax / kBfTile;
     P.tiles_per_chunk = tpc;
     P.chunk = tpc * kBfTile;
@@ -219,7 +225,7 @@ int launch_bruteforce_mfma(hipStream_t st, const BfMfmaPlan &P, const uint8_t *d
     hipLaunchKernelGGL(k_bf_expand, dim3((P.nq_pad * 16 + 255) / 256), dim3(256), 0, st, d_Q, nq, P.nq_pad, 0, P.chunk, Qx, (int32_t *)nullptr);
     hipLaunchKernelGGL(k_bf_expand, dim3((P.nt_pad * 16 + 255) / 256), dim3(256), 0, st, d_T, nt, P.nt_pad, 1, P.chunk, Tx, cinit);
     const dim3 grid(P.nq_pad / (4 * P.nq_tile * 32), P.nchunks);
-    hipLaunchKernelGGL(k_bf_mfma<2>, grid, dim3(256), 0, st, Qx, P.nq_pad, Tx, cinit, P.tiles_per_chunk, P.ntiles, part);
+    hipLaunchKernelGGL((k_bf_mfma<2, kBfStage>), grid, dim3(256), 0, st, Qx, P.nq_pad, Tx, cinit, P.tiles_per_chunk, P.ntiles, part);
     hipLaunchKernelGGL(k_bf_mfma_merge, dim3((nq + 255) / 256), dim3(256), 0, st, part, (const uint32_t *)d_Q, nq, P.nq_pad, P.nchunks, P.chunk,
                        bi, b1, b2);
     ORBGPU_HIP_CHECK(hipGetLastError());

@@ -10,9 +10,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from orb_slam2_amd import api, synth  # noqa: E402
 
+# --lib <path>: measure another build of the library (tools/build_variant.sh)
+argv = sys.argv[1:]
+if argv and argv[0] == "--lib":
+    api.LIB_PATH = os.path.abspath(argv[1])
+    argv = argv[2:]
 dev = torch.device("cuda", 0)
 m = api.ORBmatcher()
-for n in [int(a) for a in sys.argv[1:]] or [1000, 4000, 20000, 100000]:
+for n in [int(a) for a in argv] or [1000, 4000, 20000, 100000]:
     Q = torch.from_numpy(synth.descriptors(n, 5)).to(dev); T = torch.from_numpy(synth.descriptors(n, 6)).to(dev)
     out = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(6)]
     res = {"n": n}
