@@ -405,6 +405,22 @@ int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extrac
                         int32_t nR, float bf, float b, float *uRight, float *depth,
                         int32_t *nvalid);
 
+/* Frame::ComputeStereoMatches (src/Frame.cc:600-774) for npairs stereo pairs that
+ * are on the device already, asynchronous on the matcher's stream: left / right
+ * are extractor handles whose last orbgpu_extract_batch_device call processed the
+ * npairs left / right images (pair p = frame p of both calls; their pyramids are
+ * read where they lie) into d_kpsL / d_descL / d_nL with `capL` entries per pair
+ * and d_kpsR / d_descR / d_nR with `capR`.  The caller orders this call after the
+ * two extractions (same stream, or an event).  Outputs, capL entries per pair:
+ * d_uRight, d_depth (mvuRight / mvDepth; entries beyond d_nL[p] are not written)
+ * and d_nvalid[p] = left keypoints of pair p that keep a depth.  Keypoint octaves
+ * outside the pyramid are clamped into it. */
+int orbgpu_stereo_match_batch_device(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extractor *right,
+                                     int32_t npairs, const orbgpu_keypoint *d_kpsL, const uint8_t *d_descL,
+                                     const int32_t *d_nL, int32_t capL, const orbgpu_keypoint *d_kpsR,
+                                     const uint8_t *d_descR, const int32_t *d_nR, int32_t capR, float bf,
+                                     float b, float *d_uRight, float *d_depth, int32_t *d_nvalid);
+
 /* ---- Frame: device-resident frame state ----------------------------------- */
 
 /* What the constructors of Frame compute directly after the extraction

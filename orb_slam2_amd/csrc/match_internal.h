@@ -92,6 +92,11 @@ struct StereoArgs {
     float bf, b;
     float *uRight; float *depth; int32_t *best_sad;
     const int32_t *d_nL;  // non-null: the number of left keypoints is read on the device (nL is then the launch bound)
+    // Batches (grid.y = stereo pair p; all zero for a single pair): entries per pair of the left-side arrays (kpsL,
+    // descL, uRight, depth, best_sad) and of the right-side arrays, ints per pair of row_start / row_items, bytes
+    // between two frames of the extractors' pyramids; d_nL[p] is pair p's count.
+    int32_t strideL, strideR, row_stride, items_stride;
+    int64_t pyr_strideL, pyr_strideR;
 };
 
 // Frame::UndistortKeyPoints (src/Frame.cc:517-558): cv::undistortPoints(pts, K, D, R = I, P = K),

@@ -115,7 +115,13 @@ int launch_bruteforce(hipStream_t st, const uint8_t *d_Q, int nq, const uint8_t 
 __global__ __launch_bounds__(256) void k_stereo(StereoArgs A)
 {
     const int lane = lane_id(), iL = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (iL >= (A.d_nL ? min(*A.d_nL, A.nL) : A.nL)) return;
+    const int pair = blockIdx.y;
+    if (iL >= (A.d_nL ? min(A.d_nL[pair], A.nL) : A.nL)) return;
+    // this pair's slices of the batch (all strides are zero for a single pair)
+    A.kpsL += (size_t)pair * A.strideL; A.descL += (size_t)pair * A.strideL * 32;
+    A.kpsR += (size_t)pair * A.strideR; A.descR += (size_t)pair * A.strideR * 32;
+    A.row_start += (size_t)pair * A.row_stride; A.row_items += (size_t)pair * A.items_stride;
+    A.uRight += (size_t)pair * A.strideL; A.depth += (size_t)pair * A.strideL; A.best_sad += (size_t)pair * A.strideL;
     float out_u = -1.0f, out_d = -1.0f;
     int out_sad = -1;
     const orbgpu_keypoint kpL = A.kpsL[iL];
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void k_stereo(StereoArgs A)
         const int w = 5, L = 5;
         const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
         if (iniu < 0 || endu >= (float)A.w[levelL]) break;
-        const uint8_t *PL = A.pyrL[levelL], *PR = A.pyrR[levelL];
+        const uint8_t *PL = A.pyrL[levelL] + pair * A.pyr_strideL, *PR = A.pyrR[levelL] + pair * A.pyr_strideR;
         const int sL = A.pitchL[levelL], sR = A.pitchR[levelL];
         const int y0 = (int)(scaledvL - w), xL0 = (int)(scaleduL - w);
         const int cL = PL[(int64_t)(y0 + w) * sL + xL0 + w];
@@ -203,9 +209,16 @@ __global__ __launch_bounds__(256) void k_stereo(StereoArgs A)
     }
 }
 
+int launch_stereo_batch(hipStream_t st, const StereoArgs &A, int npairs);
 int launch_stereo(hipStream_t st, const StereoArgs &A)
 {
-    hipLaunchKernelGGL(k_stereo, dim3((A.nL + 3) / 4), dim3(256), 0, st, A);
+    return launch_stereo_batch(st, A, 1);
+}
+
+// `npairs` stereo pairs in one launch (grid.y = pair; the strides of StereoArgs describe the batch).
+int launch_stereo_batch(hipStream_t st, const StereoArgs &A, int npairs)
+{
+    hipLaunchKernelGGL(k_stereo, dim3((A.nL + 3) / 4, npairs), dim3(256), 0, st, A);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
@@ -222,7 +235,9 @@ __global__ __launch_bounds__(1024) void k_stereo_rows_count(const orbgpu_keypoin
     extern __shared__ int rows_lds[];  // nRows + 1 counts
     __shared__ int scan_lds[33];
     const int tid = threadIdx.x;
-    const int nR = min(max(*d_nR, 0), capR);
+    const int pair = blockIdx.x;  // a workgroup per stereo pair: arrays advance by capR / nRows + 1 entries per pair
+    kpsR += (size_t)pair * capR; spans += (size_t)pair * capR; row_start += (size_t)pair * (nRows + 1);
+    const int nR = min(max(d_nR[pair], 0), capR);
     for (int y = tid; y <= nRows; y += 1024) rows_lds[y] = 0;
     __syncthreads();
     for (int iR = tid; iR < nR; iR += 1024) {
@@ -247,11 +262,14 @@ __global__ __launch_bounds__(1024) void k_stereo_rows_count(const orbgpu_keypoin
 }
 
 __global__ __launch_bounds__(256) void k_stereo_rows_fill(const int32_t *__restrict__ spans, const int32_t *__restrict__ d_nR, int capR,
-                                                          int nRows, const int32_t *__restrict__ row_start, int32_t *__restrict__ row_items)
+                                                          int nRows, const int32_t *__restrict__ row_start, int32_t *__restrict__ row_items,
+                                                          int items_stride)
 {
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
     if (y >= nRows) return;
-    const int nR = min(max(*d_nR, 0), capR);
+    const int pair = blockIdx.y;
+    spans += (size_t)pair * capR; row_start += (size_t)pair * (nRows + 1); row_items += (size_t)pair * items_stride;
+    const int nR = min(max(d_nR[pair], 0), capR);
     int cur = row_start[y];
     for (int base = 0; base < nR; base += 64) {
         const int iR = base + lane;
@@ -269,21 +287,25 @@ __global__ __launch_bounds__(256) void k_stereo_rows_fill(const int32_t *__restr
 
 // Outlier rejection of ComputeStereoMatches (src/Frame.cc:760-773): the median of the matched SADs is element
 // size / 2 of their ascending order; matches with SAD >= 1.5 * 1.4 * median lose their measurement.  The SAD of an
-// 11 x 11 window of bytes is below 2^15: the median comes out of a histogram of the high eight bits and one of the
-// low seven bits inside the bucket that holds it.
+// 11 x 11 window of centre-subtracted bytes is at most 121 * 510 = 61 710 < 2^16: the median comes out of a
+// histogram of the high eight bits and one of the low eight bits inside the bucket that holds it.  A workgroup per
+// stereo pair (the arrays advance by capL entries per pair).
 __global__ __launch_bounds__(1024) void k_stereo_outliers(const int32_t *__restrict__ best_sad, const int32_t *__restrict__ d_nL, int capL,
-                                                          float *__restrict__ uRight, float *__restrict__ depth, int32_t *__restrict__ nvalid_out)
+                                                          float *__restrict__ uRight, float *__restrict__ depth, int32_t *__restrict__ nvalid_out,
+                                                          int nL_stride, int nvalid_stride)
 {
     __shared__ int hist[256];
     __shared__ int removed;
     const int tid = threadIdx.x;
-    const int n = min(max(*d_nL, 0), capL);
+    const int pair = blockIdx.x;
+    best_sad += (size_t)pair * capL; uRight += (size_t)pair * capL; depth += (size_t)pair * capL; nvalid_out += pair * nvalid_stride;
+    const int n = min(max(d_nL[pair * nL_stride], 0), capL);
     if (tid < 256) hist[tid] = 0;
     if (tid == 0) removed = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const int s = best_sad[i];
-        if (s >= 0) atomicAdd(&hist[min(s >> 7, 255)], 1);
+        if (s >= 0) atomicAdd(&hist[min(s >> 8, 255)], 1);
     }
     __syncthreads();
     // every thread walks the histogram itself (broadcast reads): the number of matches, the bucket of the median and
@@ -301,19 +323,19 @@ __global__ __launch_bounds__(1024) void k_stereo_outliers(const int32_t *__restr
         acc += hist[b];
     }
     __syncthreads();
-    if (tid < 128) hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const int s = best_sad[i];
-        if (s >= 0 && min(s >> 7, 255) == b) atomicAdd(&hist[s & 127], 1);
+        if (s >= 0 && min(s >> 8, 255) == b) atomicAdd(&hist[s & 255], 1);
     }
     __syncthreads();
     int lo = 0;
-    for (; lo < 127; lo++) {
+    for (; lo < 255; lo++) {
         if (kmed < acc + hist[lo]) break;
         acc += hist[lo];
     }
-    const int bucket = (b << 7) | lo;
+    const int bucket = (b << 8) | lo;
     const float median = (float)bucket;
     const float thDist = __fmul_rn(1.5f * 1.4f, median);
     int mine = 0;
@@ -330,12 +352,31 @@ __global__ __launch_bounds__(1024) void k_stereo_outliers(const int32_t *__restr
     if (tid == 0) *nvalid_out = total - removed;
 }
 
+// npairs row tables in two launches: pair p's right keypoints at kpsR + p * capR with count d_nR[p], its spans at
+// spans + p * capR, row starts at row_start + p * (nRows + 1), row lists at row_items + p * items_stride.
+int launch_stereo_rows_batch(hipStream_t st, int npairs, const orbgpu_keypoint *kpsR, const int32_t *d_nR, int capR, const ScaleTab &scale,
+                             int nlevels, int nRows, int32_t *spans, int32_t *row_start, int32_t *row_items, int items_stride)
+{
+    hipLaunchKernelGGL(k_stereo_rows_count, dim3(npairs), dim3(1024), ((size_t)nRows + 1) * 4, st, kpsR, d_nR, capR, scale, nlevels, nRows,
+                       spans, row_start);
+    hipLaunchKernelGGL(k_stereo_rows_fill, dim3((nRows + 3) / 4, npairs), dim3(256), 0, st, spans, d_nR, capR, nRows, row_start, row_items,
+                       items_stride);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
 int launch_stereo_rows(hipStream_t st, const orbgpu_keypoint *kpsR, const int32_t *d_nR, int capR, const ScaleTab &scale, int nlevels, int nRows,
                        int32_t *spans, int32_t *row_start, int32_t *row_items)
 {
-    hipLaunchKernelGGL(k_stereo_rows_count, dim3(1), dim3(1024), ((size_t)nRows + 1) * 4, st, kpsR, d_nR, capR, scale, nlevels, nRows, spans,
-                       row_start);
-    hipLaunchKernelGGL(k_stereo_rows_fill, dim3((nRows + 3) / 4), dim3(256), 0, st, spans, d_nR, capR, nRows, row_start, row_items);
+    return launch_stereo_rows_batch(st, 1, kpsR, d_nR, capR, scale, nlevels, nRows, spans, row_start, row_items, 0);
+}
+
+// npairs outlier cuts: pair p's arrays at + p * capL, its count at d_nL[p * nL_stride], its result at nvalid[p * nvalid_stride].
+int launch_stereo_outliers_batch(hipStream_t st, int npairs, const int32_t *best_sad, const int32_t *d_nL, int nL_stride, int capL,
+                                 float *uRight, float *depth, int32_t *nvalid, int nvalid_stride)
+{
+    hipLaunchKernelGGL(k_stereo_outliers, dim3(npairs), dim3(1024), 0, st, best_sad, d_nL, capL, uRight, depth, nvalid, nL_stride,
+                       nvalid_stride);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
@@ -343,9 +384,7 @@ int launch_stereo_rows(hipStream_t st, const orbgpu_keypoint *kpsR, const int32_
 int launch_stereo_outliers(hipStream_t st, const int32_t *best_sad, const int32_t *d_nL, int capL, float *uRight, float *depth,
                            int32_t *nvalid)
 {
-    hipLaunchKernelGGL(k_stereo_outliers, dim3(1), dim3(1024), 0, st, best_sad, d_nL, capL, uRight, depth, nvalid);
-    ORBGPU_HIP_CHECK(hipGetLastError());
-    return ORBGPU_OK;
+    return launch_stereo_outliers_batch(st, 1, best_sad, d_nL, 0, capL, uRight, depth, nvalid, 0);
 }
 
 // ---------------------------------------------------------------------------

@@ -23,6 +23,11 @@ int launch_stereo_rows(hipStream_t st, const orbgpu_keypoint *kpsR, const int32_
                        int32_t *spans, int32_t *row_start, int32_t *row_items);
 int launch_stereo_outliers(hipStream_t st, const int32_t *best_sad, const int32_t *d_nL, int capL, float *uRight, float *depth,
                            int32_t *nvalid);
+int launch_stereo_batch(hipStream_t st, const StereoArgs &A, int npairs);
+int launch_stereo_rows_batch(hipStream_t st, int npairs, const orbgpu_keypoint *kpsR, const int32_t *d_nR, int capR, const ScaleTab &scale,
+                             int nlevels, int nRows, int32_t *spans, int32_t *row_start, int32_t *row_items, int items_stride);
+int launch_stereo_outliers_batch(hipStream_t st, int npairs, const int32_t *best_sad, const int32_t *d_nL, int nL_stride, int capL,
+                                 float *uRight, float *depth, int32_t *nvalid, int nvalid_stride);
 int launch_init_queries(hipStream_t st, const orbgpu_keypoint *kps1, int n1, const float *prev_xy, int window, orbgpu_wquery *q);
 int launch_init_update(hipStream_t st, const int32_t *matches12, int n1, const orbgpu_keypoint *kps2, float *prev_xy);
 int launch_distinctive(hipStream_t st, const uint8_t *d_desc, const int32_t *d_start, int npoints, int32_t *d_best_idx,
@@ -99,6 +104,7 @@ struct orbgpu_matcher {
     MBuf bfws;     // matrix-core brute force: byte-per-bit images of both descriptor sets and the chunks' partial results
     int bf_kernel = 0;  // 0: chosen by size, 1: vector-unit kernel, 2: matrix-core kernel (orbgpu_matcher_set_bruteforce_kernel)
     MBuf scratch;  // window matcher scratch
+    MBuf stereo;   // batched ComputeStereoMatches: best SADs, row spans, row tables
     MBuf stats;    // resolver statistics of the last window call
     int stats_pairs = 0;
     MBuf stage[12];  // staging for the host entry points
@@ -212,6 +218,7 @@ void orbgpu_matcher_destroy(orbgpu_matcher *m)
     m->part.release();
     m->bfws.release();
     m->scratch.release();
+    m->stereo.release();
     m->stats.release();
     for (auto &b : m->stage) b.release();
     m->io.release();
@@ -907,6 +914,79 @@ int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extrac
     memcpy(depth, hb + (o_dp - o_ur), (size_t)nL * 4);
     *nvalid = *(const int32_t *)(hb + (o_nv - o_ur));
     return ORBGPU_OK;
+}
+
+// Frame::ComputeStereoMatches (src/Frame.cc:600-774) for a batch of stereo pairs whose keypoints, descriptors and
+// pyramids are on the device: five launches for the whole batch (row spans + row starts, row lists, matching with the
+// sub-pixel refinement, outlier cut), every one with the pair as a grid dimension.
+int orbgpu_stereo_match_batch_device(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extractor *right, int32_t npairs,
+                                     const orbgpu_keypoint *d_kpsL, const uint8_t *d_descL, const int32_t *d_nL, int32_t capL,
+                                     const orbgpu_keypoint *d_kpsR, const uint8_t *d_descR, const int32_t *d_nR, int32_t capR,
+                                     float bf, float b, float *d_uRight, float *d_depth, int32_t *d_nvalid)
+{
+    if (!m || !left || !right || left == right || npairs < 1 || capL < 1 || capR < 1 || !d_kpsL || !d_descL || !d_nL || !d_kpsR ||
+        !d_descR || !d_nR || !d_uRight || !d_depth || !d_nvalid || !(b > 0)) {
+        set_error("orbgpu_stereo_match_batch_device: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    StereoArgs A;
+    memset(&A, 0, sizeof(A));
+    int32_t nlev = 0, nlevR = 0;
+    float scaleR[ORBGPU_MAX_LEVELS];
+    int rc;
+    if ((rc = orbgpu_extractor_tables(left, &nlev, A.scale, A.inv_scale, nullptr, nullptr, nullptr))) return rc;
+    if ((rc = orbgpu_extractor_tables(right, &nlevR, scaleR, nullptr, nullptr, nullptr, nullptr))) return rc;
+    if (nlevR != nlev || memcmp(scaleR, A.scale, sizeof(float) * (size_t)nlev) != 0) {
+        set_error("orbgpu_stereo_match_batch_device: the two extractors have different pyramids");
+        return ORBGPU_E_INVALID;
+    }
+    A.nlevels = nlev;
+    for (int l = 0; l < nlev; l++) {
+        int32_t w2, h2, p2;
+        // frame npairs - 1 must exist in both extractors' last call
+        const uint8_t *lastL, *lastR;
+        if ((rc = orbgpu_pyramid_level_device(left, npairs - 1, l, 0, &lastL, nullptr, nullptr, nullptr))) return rc;
+        if ((rc = orbgpu_pyramid_level_device(right, npairs - 1, l, 0, &lastR, nullptr, nullptr, nullptr))) return rc;
+        if ((rc = orbgpu_pyramid_level_device(left, 0, l, 0, &A.pyrL[l], &A.pitchL[l], &A.w[l], &A.h[l]))) return rc;
+        if ((rc = orbgpu_pyramid_level_device(right, 0, l, 0, &A.pyrR[l], &p2, &w2, &h2))) return rc;
+        A.pitchR[l] = p2;
+        if (w2 != A.w[l] || h2 != A.h[l]) {
+            set_error("left and right pyramids differ at level %d", l);
+            return ORBGPU_E_INVALID;
+        }
+        if (l == 0 && npairs > 1) {
+            A.pyr_strideL = (lastL - A.pyrL[0]) / (npairs - 1);
+            A.pyr_strideR = (lastR - A.pyrR[0]) / (npairs - 1);
+        }
+    }
+    if (A.h[0] > 8192) {
+        set_error("orbgpu_stereo_match_batch_device: images of more than 8192 rows are not supported");
+        return ORBGPU_E_UNSUPPORTED;
+    }
+    const int nRows = A.h[0];
+    const size_t span = (size_t)ceilf(4.0f * A.scale[nlev - 1]) + 3;  // a right keypoint lies in at most 2 r + 3 rows, r = 2 * scale
+    const size_t items = (size_t)capR * (span < (size_t)nRows ? span : (size_t)nRows);
+    if (items > 0x7FFFFFFF) {
+        set_error("orbgpu_stereo_match_batch_device: the row tables of one pair exceed 2^31 entries");
+        return ORBGPU_E_UNSUPPORTED;
+    }
+    // per pair: best SAD [capL] | row spans [capR] | row starts [nRows + 1] | row lists [items]
+    const size_t n_sad = (size_t)npairs * capL, n_sp = (size_t)npairs * capR, n_rs = (size_t)npairs * (nRows + 1), n_ri = (size_t)npairs * items;
+    if ((rc = m->stereo.ensure((n_sad + n_sp + n_rs + n_ri) * 4))) return rc;
+    int32_t *best_sad = (int32_t *)m->stereo.p, *spans = best_sad + n_sad, *row_start = spans + n_sp, *row_items = row_start + n_rs;
+    hipStream_t st = m->stream;
+    ScaleTab sc;
+    for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) sc.s[l] = A.scale[l < nlev ? l : nlev - 1];
+    if ((rc = launch_stereo_rows_batch(st, npairs, d_kpsR, d_nR, capR, sc, nlev, nRows, spans, row_start, row_items, (int)items))) return rc;
+    A.kpsL = d_kpsL; A.descL = d_descL; A.nL = capL; A.d_nL = d_nL;
+    A.kpsR = d_kpsR; A.descR = d_descR; A.nR = capR;
+    A.row_start = row_start; A.row_items = row_items; A.nRows = nRows;
+    A.bf = bf; A.b = b;
+    A.uRight = d_uRight; A.depth = d_depth; A.best_sad = best_sad;
+    A.strideL = capL; A.strideR = capR; A.row_stride = nRows + 1; A.items_stride = (int32_t)items;
+    if ((rc = launch_stereo_batch(st, A, npairs))) return rc;
+    return launch_stereo_outliers_batch(st, npairs, best_sad, d_nL, 1, capL, d_uRight, d_depth, d_nvalid, 1);
 }
 
 // ---- the same searches with a device-resident frame as the train side ------------------------------------------

@@ -382,6 +382,57 @@ def test_stereo_matches_kitti_geometry(oracle):
     assert np.mean(np.abs((kL["x"][ok] - uR[ok]) - d_true) < 1.5) > 0.8
 
 
+@pytest.mark.parametrize("w,h,nfeat,bf,fx,seeds", [(752, 480, 1200, 47.90639384423901, 435.2046959714599, (3, 13, 23, 33, 43)),
+                                                  (1241, 376, 2000, 386.1448, 718.856, (2, 12, 22))])
+def test_stereo_matches_batch_device(oracle, w, h, nfeat, bf, fx, seeds):
+    """orbgpu_stereo_match_batch_device: every pair of a device-resident batch equals the oracle's ComputeStereoMatches
+    on that pair's own arrays and the single-pair entry point; the last pair is an empty right image (no matches)."""
+    from hiputil import Hip
+    from orb_slam2_amd.api import KEYPOINT_DTYPE, ORBextractor, ORBmatcher
+    pairs = [synth.stereo_pair(w, h, seed=s)[:2] for s in seeds]
+    pairs.append((pairs[0][0], np.full((h, w), 90, np.uint8)))  # flat right image: no right keypoints
+    B = len(pairs)
+    exL = ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    exR = ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    m = ORBmatcher()
+    cap = exL.max_keypoints
+    hip = Hip()
+    try:
+        imgs = [hip.upload(np.stack([p[i] for p in pairs])) for i in range(2)]
+        kk = [hip.alloc(B * cap * 28) for _ in range(2)]; dd = [hip.alloc(B * cap * 32) for _ in range(2)]
+        cc = [hip.alloc(B * 4) for _ in range(2)]
+        uR = hip.upload(np.full((B, cap), -7.0, np.float32)); dep = hip.upload(np.full((B, cap), -7.0, np.float32))
+        nv = hip.alloc(B * 4)
+        for ex, i in ((exL, 0), (exR, 1)):
+            ex.extract_batch_device(imgs[i].value, B, w, h, w, w * h, kk[i].value, dd[i].value, cap, cc[i].value)
+            ex.sync()
+        m.stereo_match_batch_device(exL, exR, B, kk[0].value, dd[0].value, cc[0].value, cap, kk[1].value, dd[1].value, cc[1].value, cap,
+                                    bf, bf / fx, uR.value, dep.value, nv.value)
+        m.sync()
+        nL, nR = hip.download(cc[0], B, np.int32), hip.download(cc[1], B, np.int32)
+        K = [hip.download(kk[i], (B, cap), KEYPOINT_DTYPE) for i in range(2)]
+        D = [hip.download(dd[i], (B, cap, 32), np.uint8) for i in range(2)]
+        UR, DEP, NV = hip.download(uR, (B, cap), np.float32), hip.download(dep, (B, cap), np.float32), hip.download(nv, B, np.int32)
+    finally:
+        hip.free()
+    t = oracle.tables(oracle.make_params(nfeat))
+    assert nR[B - 1] == 0 and NV[B - 1] == 0
+    total = 0
+    for p in range(B):
+        kL, kR, desL, desR = K[0][p, :nL[p]], K[1][p, :nR[p]], D[0][p, :nL[p]], D[1][p, :nR[p]]
+        pyrL = [exL.pyramid_level(l, frame=p) for l in range(8)]; pyrR = [exR.pyramid_level(l, frame=p) for l in range(8)]
+        rn, ruR, rdep = oracle.stereo_matches(kL.view(oracle.KEYPOINT_DTYPE), desL, kR.view(oracle.KEYPOINT_DTYPE), desR, pyrL, pyrR,
+                                              t["scale"], t["inv_scale"], bf, bf / fx)
+        assert NV[p] == rn
+        assert np.array_equal(UR[p, :nL[p]], ruR) and np.array_equal(DEP[p, :nL[p]], rdep)
+        assert (UR[p, nL[p]:] == -7.0).all()  # nothing written beyond the pair's keypoints
+        if p < 2:  # the single-pair entry point on the same arrays and pyramids
+            sn, suR, sdep = m.ComputeStereoMatches(exL, exR, kL, desL, kR, desR, bf, bf / fx, frame=p)
+            assert sn == rn and np.array_equal(suR, ruR) and np.array_equal(sdep, rdep)
+        total += rn
+    assert total > 100 * (B - 1)
+
+
 def test_bruteforce_100k_properties(matcher):
     """Large brute-force case: 100k x 100k.  Checked through size-independent properties
     (planted partner recovery, self-match, distance symmetry on a sample)."""
