@@ -395,6 +395,19 @@ int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *k
                                      int32_t *matches12, int32_t window_size, float nnratio,
                                      int32_t check_orientation, int32_t *nmatches);
 
+/* SearchForInitialization for npairs frame pairs on the device, asynchronous on
+ * the matcher's stream: pair p matches frame 1 [p] (capacity1 entries per pair,
+ * d_n1[p] valid) against frame 2 [p], with vbPrevMatched = frame 1's own keypoint
+ * positions, the state in which Tracking starts an initialisation
+ * (src/Tracking.cc:592-594) -- the batch form has no carried vbPrevMatched.
+ * d_matches12: capacity1 entries per pair (vnMatches12; entries beyond d_n1[p] are
+ * not written); d_nmatches[p] = the reference's return value. */
+int orbgpu_search_for_initialization_batch_device(
+    orbgpu_matcher *m, int32_t npairs, const orbgpu_keypoint *d_kps1, const uint8_t *d_desc1,
+    const int32_t *d_n1, int32_t capacity1, const orbgpu_keypoint *d_kps2, const uint8_t *d_desc2,
+    const int32_t *d_n2, int32_t capacity2, const float *bounds4_host, int32_t window_size,
+    float nnratio, int32_t check_orientation, int32_t *d_matches12, int32_t *d_nmatches);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:600-774).  left/right are
  * extractor handles whose last extract call processed the stereo pair (frame
  * index `frame` of that call); keypoints/descriptors are the host outputs of

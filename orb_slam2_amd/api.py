@@ -41,7 +41,7 @@ EXPORTS = [
     "orbgpu_search_by_projection", "orbgpu_debug_window_stats", "orbgpu_search_by_projection_batch_device", "orbgpu_make_shift_queries_device",
     "orbgpu_search_by_bow", "orbgpu_search_for_triangulation", "orbgpu_search_in_area", "orbgpu_assign_features_to_grid",
     "orbgpu_distinctive_descriptors", "orbgpu_stereo_from_rgbd", "orbgpu_undistort_keypoints", "orbgpu_search_for_initialization", "orbgpu_stereo_match",
-    "orbgpu_stereo_match_batch_device",
+    "orbgpu_stereo_match_batch_device", "orbgpu_search_for_initialization_batch_device",
     "orbgpu_frame_create", "orbgpu_frame_destroy", "orbgpu_frame_build_mono", "orbgpu_frame_build_rgbd", "orbgpu_frame_build_stereo", "orbgpu_frame_upload",
     "orbgpu_frame_size", "orbgpu_frame_download", "orbgpu_frame_grid", "orbgpu_frame_device",
     "orbgpu_search_by_projection_frame", "orbgpu_search_in_area_frame", "orbgpu_search_by_bow_frame",
@@ -124,6 +124,7 @@ def load_library():
         L.orbgpu_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32,
                                                        C.POINTER(i32)]
         L.orbgpu_stereo_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
+        L.orbgpu_search_for_initialization_batch_device.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, f32, i32, vp, vp]
         L.orbgpu_stereo_match_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, f32, f32, vp, vp, vp]
         L.orbgpu_frame_create.argtypes = [i32, i32, C.POINTER(vp)]
         L.orbgpu_frame_destroy.argtypes = [vp]
@@ -697,6 +698,15 @@ class ORBmatcher:
                                              _p(kpsR), _p(descR), len(kpsR), bf, b, _p(uR), _p(dep), C.byref(n)),
                "orbgpu_stereo_match")
         return n.value, uR[:len(kpsL)].copy(), dep[:len(kpsL)].copy()
+
+    def search_for_initialization_batch_device(self, npairs, d_kps1, d_desc1, d_n1, cap1, d_kps2, d_desc2, d_n2, cap2, bounds, d_matches12,
+                                               d_nmatches, windowSize=100):
+        """orbgpu_search_for_initialization_batch_device: device pointers as integers, asynchronous on the matcher's stream."""
+        v = C.c_void_p
+        b = np.asarray(bounds, np.float32)
+        _check(self._lib.orbgpu_search_for_initialization_batch_device(
+            self._h, npairs, v(d_kps1), v(d_desc1), v(d_n1), cap1, v(d_kps2), v(d_desc2), v(d_n2), cap2, _p(b), windowSize,
+            self.mfNNratio, int(self.mbCheckOrientation), v(d_matches12), v(d_nmatches)), "orbgpu_search_for_initialization_batch_device")
 
     def stereo_match_batch_device(self, left, right, npairs, d_kpsL, d_descL, d_nL, capL, d_kpsR, d_descR, d_nR, capR, bf, b,
                                   d_uRight, d_depth, d_nvalid):

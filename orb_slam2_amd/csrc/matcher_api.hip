@@ -30,6 +30,8 @@ int launch_stereo_outliers_batch(hipStream_t st, int npairs, const int32_t *best
                                  float *uRight, float *depth, int32_t *nvalid, int nvalid_stride);
 int launch_init_queries(hipStream_t st, const orbgpu_keypoint *kps1, int n1, const float *prev_xy, int window, orbgpu_wquery *q);
 int launch_init_update(hipStream_t st, const int32_t *matches12, int n1, const orbgpu_keypoint *kps2, float *prev_xy);
+int launch_init_queries_batch(hipStream_t st, int npairs, const orbgpu_keypoint *kps1, const int32_t *n1, int capacity, int window,
+                              orbgpu_wquery *q);
 int launch_distinctive(hipStream_t st, const uint8_t *d_desc, const int32_t *d_start, int npoints, int32_t *d_best_idx,
                        int32_t *d_best_median);
 int launch_undistort(hipStream_t st, const orbgpu_keypoint *kps, int n, const float *K4, const float *D5, orbgpu_keypoint *out);
@@ -105,6 +107,7 @@ struct orbgpu_matcher {
     int bf_kernel = 0;  // 0: chosen by size, 1: vector-unit kernel, 2: matrix-core kernel (orbgpu_matcher_set_bruteforce_kernel)
     MBuf scratch;  // window matcher scratch
     MBuf stereo;   // batched ComputeStereoMatches: best SADs, row spans, row tables
+    MBuf initws;   // batched SearchForInitialization: queries and the per-train-keypoint assignment
     MBuf stats;    // resolver statistics of the last window call
     int stats_pairs = 0;
     MBuf stage[12];  // staging for the host entry points
@@ -219,6 +222,7 @@ void orbgpu_matcher_destroy(orbgpu_matcher *m)
     m->bfws.release();
     m->scratch.release();
     m->stereo.release();
+    m->initws.release();
     m->stats.release();
     for (auto &b : m->stage) b.release();
     m->io.release();
@@ -794,6 +798,30 @@ int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *k
             prev_matched_xy[2 * i + 1] = kps2[matches12[i]].y;
         }
     return ORBGPU_OK;
+}
+
+// SearchForInitialization (src/ORBmatcher.cc:422-571) for a batch of frame pairs on the device, each with
+// vbPrevMatched = frame 1's own keypoint positions (the state at the start of an initialisation).
+int orbgpu_search_for_initialization_batch_device(orbgpu_matcher *m, int32_t npairs, const orbgpu_keypoint *d_kps1,
+                                                  const uint8_t *d_desc1, const int32_t *d_n1, int32_t capacity1,
+                                                  const orbgpu_keypoint *d_kps2, const uint8_t *d_desc2, const int32_t *d_n2,
+                                                  int32_t capacity2, const float *bounds4_host, int32_t window_size, float nnratio,
+                                                  int32_t check_orientation, int32_t *d_matches12, int32_t *d_nmatches)
+{
+    if (!m || npairs < 1 || capacity1 < 1 || capacity2 < 1 || !d_kps1 || !d_desc1 || !d_n1 || !d_kps2 || !d_desc2 || !d_n2 ||
+        !bounds4_host || !d_matches12 || !d_nmatches) {
+        set_error("orbgpu_search_for_initialization_batch_device: invalid argument");
+        return ORBGPU_E_INVALID;
+    }
+    ORBGPU_HIP_CHECK(hipSetDevice(m->device));
+    const size_t qbytes = ((size_t)npairs * capacity1 * sizeof(orbgpu_wquery) + 255) & ~(size_t)255;
+    int rc = m->initws.ensure(qbytes + (size_t)npairs * capacity2 * 4);
+    if (rc) return rc;
+    orbgpu_wquery *q = (orbgpu_wquery *)m->initws.p;
+    int32_t *assign = (int32_t *)((uint8_t *)m->initws.p + qbytes);
+    if ((rc = launch_init_queries_batch(m->stream, npairs, d_kps1, d_n1, capacity1, window_size, q))) return rc;
+    return run_window(m, 3, npairs, q, d_desc1, d_n1, capacity1, d_kps2, d_desc2, nullptr, d_n2, capacity2, bounds4_host, nullptr,
+                      assign, d_matches12, ORBGPU_TH_LOW, nnratio, check_orientation, d_nmatches);
 }
 
 int orbgpu_make_shift_queries_device(orbgpu_matcher *m, int32_t npairs, const orbgpu_keypoint *d_kps_last,

@@ -1049,6 +1049,34 @@ int launch_init_queries(hipStream_t st, const orbgpu_keypoint *kps1, int n1, con
     return ORBGPU_OK;
 }
 
+// The same queries for a batch of frame pairs, with vbPrevMatched = the keypoints' own positions (what Tracking sets
+// when it starts an initialisation, src/Tracking.cc:592-594): pair p's keypoints at kps1 + p * capacity, n1[p] valid.
+__global__ __launch_bounds__(256) void k_init_queries_batch(const orbgpu_keypoint *__restrict__ kps1, const int32_t *__restrict__ n1,
+                                                            int capacity, int window, orbgpu_wquery *__restrict__ q)
+{
+    const int pair = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(n1[pair], capacity)) return;
+    const orbgpu_keypoint kp = kps1[(size_t)pair * capacity + i];
+    orbgpu_wquery w;
+    w.u = kp.x;
+    w.v = kp.y;
+    w.r = (float)window;
+    w.minLevel = kp.octave;
+    w.maxLevel = kp.octave;
+    w.angle = kp.angle;
+    w.ur = -1.0f;
+    w.flags = kp.octave > 0 ? 0 : 1;
+    q[(size_t)pair * capacity + i] = w;
+}
+
+int launch_init_queries_batch(hipStream_t st, int npairs, const orbgpu_keypoint *kps1, const int32_t *n1, int capacity, int window,
+                              orbgpu_wquery *q)
+{
+    hipLaunchKernelGGL(k_init_queries_batch, dim3((capacity + 255) / 256, npairs), dim3(256), 0, st, kps1, n1, capacity, window, q);
+    ORBGPU_HIP_CHECK(hipGetLastError());
+    return ORBGPU_OK;
+}
+
 int launch_init_update(hipStream_t st, const int32_t *matches12, int n1, const orbgpu_keypoint *kps2, float *prev_xy)
 {
     hipLaunchKernelGGL(k_init_update, dim3((n1 + 255) / 256), dim3(256), 0, st, matches12, n1, kps2, prev_xy);

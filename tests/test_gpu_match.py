@@ -507,6 +507,49 @@ def test_batch_device_many_pairs(oracle, frames, mode, th, tcap):
     assert NM.sum() > 5000
 
 
+@pytest.mark.parametrize("npairs,window", [(3, 100), (70, 100), (70, 10)])
+def test_search_for_initialization_batch_device(oracle, frames, npairs, window):
+    """orbgpu_search_for_initialization_batch_device: every pair equals the oracle's SearchForInitialization started from
+    vbPrevMatched = frame 1's keypoint positions; pairs of different sizes, one with no level-0 keypoints, one empty."""
+    from orb_slam2_amd import api
+    from hiputil import Hip
+    m = api.ORBmatcher(0.9, True)
+    b = _bounds()
+    cap1, cap2 = 1100, 1150
+    rng = np.random.default_rng(7 + npairs)
+    K1 = np.zeros((npairs, cap1), api.KEYPOINT_DTYPE); D1 = np.zeros((npairs, cap1, 32), np.uint8)
+    K2 = np.zeros((npairs, cap2), api.KEYPOINT_DTYPE); D2 = np.zeros((npairs, cap2, 32), np.uint8)
+    N1 = np.zeros(npairs, np.int32); N2 = np.zeros(npairs, np.int32)
+    refs = []
+    for p in range(npairs):
+        (ka, da), (kb, db) = frames[p % 2], frames[p % 2 + 1]
+        keep = np.sort(rng.choice(len(ka), size=int(rng.integers(1, len(ka) + 1)), replace=False)) if p else np.arange(len(ka))
+        ka, da = ka[keep], da[keep]
+        if p == 1:
+            ka = ka[ka["octave"] > 0]; da = da[:len(ka)]  # no level-0 keypoints: nothing to match
+        if p == 2:
+            kb, db = kb[:0], db[:0]                          # an empty second frame
+        K1[p, :len(ka)] = ka; D1[p, :len(ka)] = da; N1[p] = len(ka)
+        K2[p, :len(kb)] = kb; D2[p, :len(kb)] = db; N2[p] = len(kb)
+        prev = np.stack([ka["x"], ka["y"]], axis=1).astype(np.float32).reshape(-1)
+        refs.append(oracle.search_for_initialization(ka.view(oracle.KEYPOINT_DTYPE), da, kb.view(oracle.KEYPOINT_DTYPE), db, b, prev,
+                                                     windowSize=window, nnratio=0.9, checkOri=True))
+    hip = Hip()
+    try:
+        dK1, dD1, dN1, dK2, dD2, dN2 = [hip.upload(a) for a in (K1, D1, N1, K2, D2, N2)]
+        dM = hip.upload(np.full((npairs, cap1), -9, np.int32)); dNM = hip.alloc(npairs * 4)
+        m.search_for_initialization_batch_device(npairs, dK1.value, dD1.value, dN1.value, cap1, dK2.value, dD2.value, dN2.value, cap2, b,
+                                                 dM.value, dNM.value, windowSize=window)
+        m.sync()
+        M = hip.download(dM, (npairs, cap1), np.int32); NM = hip.download(dNM, npairs, np.int32)
+    finally:
+        hip.free()
+    for p, (rn, rm12, _) in enumerate(refs):
+        assert NM[p] == rn, "pair %d" % p
+        assert np.array_equal(M[p, :N1[p]], rm12), "pair %d" % p
+    assert NM[1] == 0 and NM[2] == 0 and NM.sum() > 20 * (npairs - 2)
+
+
 @pytest.mark.parametrize("which", ["in_area", "projection"])
 def test_keyframe_grid_geometry(matcher, oracle, frames, which):
     """A KeyFrame keeps its Frame's grid (binned with the Frame's float bounds) but computes query cell ranges from
