@@ -35,18 +35,19 @@ def _canvas(w, h, seed, n_shapes, smax=None):
     return img
 
 
-def sequence(w, h, n_frames, seed=1, n_shapes=None, noise=3.0, step=(2, 1), per_frame_density=False):
+def sequence(w, h, n_frames, seed=1, n_shapes=None, noise=3.0, step=(2, 1), per_frame_density=False, smax=None):
     """Return uint8 array [n_frames, h, w]; frame k = canvas crop shifted by k*step.
     n_shapes counts the shapes drawn on the whole canvas; with per_frame_density it is the number per frame-sized
-    area instead (long sequences travel over a canvas many frames large and would otherwise thin out)."""
+    area instead (long sequences travel over a canvas many frames large and would otherwise thin out).  smax bounds
+    the half-size of a shape (default: a sixth of the smaller image side; large images want many small shapes to
+    fill a feature budget that grows with their area)."""
     if n_shapes is None:
         n_shapes = max(60, (w * h) // 768)
     mx = abs(step[0]) * n_frames + 8
     my = abs(step[1]) * n_frames + 8
-    smax = None
     if per_frame_density:
         n_shapes = int(round(n_shapes * float((w + mx) * (h + my)) / float(w * h)))
-        smax = max(8, min(w, h) // 6)  # shape sizes of a frame-sized canvas
+        smax = smax or max(8, min(w, h) // 6)  # shape sizes of a frame-sized canvas
     can = _canvas(w + mx, h + my, seed, n_shapes, smax)
     rng = np.random.default_rng(seed + 7919)
     out = np.empty((n_frames, h, w), np.uint8)

@@ -15,7 +15,9 @@ from orb_slam2_amd.dist import max_over_ranks, shard_frames, sum_over_ranks  # n
 
 def main():
     import torch.distributed as dist
-    rank, local_rank, world = bench.init_ranks("gloo")
+    # STUB_BACKEND=nccl on a box without GPUs: the RCCL group cannot start and init_ranks must fall back to gloo
+    rank, local_rank, world = bench.init_ranks(os.environ.get("STUB_BACKEND", "gloo"))
+    assert bench.BACKEND["name"] == "gloo" and bench.reduce_device("cuda:0") is None
     assert local_rank == rank and world == int(os.environ["WORLD_SIZE"])
     total = 256
     mine = shard_frames(total, world, rank)
@@ -32,7 +34,7 @@ def main():
     if rank == 0:
         line = bench.bench_line("stub", "frames/s", total * 5 / wall_max, world, 5, 2, wall_max, "strong", "u8", "none",
                                 {"workload": "stub", "first": mine[0], "last": mine[-1], "covered": covered,
-                                 "slowest_rank_s": wall_max, "this_rank_s": wall})
+                                 "slowest_rank_s": wall_max, "this_rank_s": wall, "backend": bench.BACKEND["name"]})
         print(json.dumps(line), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -62,6 +62,18 @@ def test_bench_launcher_starts_ranks_and_relays_rank0():
     assert abs(line["ms_per_step"] - cfg["slowest_rank_s"] / 5 * 1e3) < 1e-9
 
 
+def test_bench_ranks_fall_back_to_gloo_when_rccl_cannot_start():
+    """The ranks ask for the nccl (RCCL) backend on a machine where it cannot start (no GPU here): every rank must fall
+    back to gloo, report so, and the timed region, the max over ranks and rank 0's line must come out as usual."""
+    import json
+    import bench
+    rc, out = bench.spawn_ranks(2, [sys.executable, os.path.join(ROOT, "tests", "stub_bench_rank.py")], extra_env={"STUB_BACKEND": "nccl"},
+                                timeout=300)
+    assert rc == 0, out
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["backend"] == "gloo" and line["config"]["covered"] == 256.0
+
+
 def test_bench_launcher_reports_a_failing_rank():
     import bench
     rc, _ = bench.spawn_ranks(2, [sys.executable, "-c", "import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)"], timeout=60)
