@@ -112,19 +112,21 @@ int launch_bruteforce(hipStream_t st, const uint8_t *d_Q, int nq, const uint8_t 
 // fit the parabola.  The row table (:610-627) and the median-based outlier rejection (:760-773) are
 // the kernels after this one.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stereo(StereoArgs A)
+__global__ __launch_bounds__(256) void k_stereo(const StereoArgs A)
 {
     const int lane = lane_id(), iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int pair = blockIdx.y;
     if (iL >= (A.d_nL ? min(A.d_nL[pair], A.nL) : A.nL)) return;
-    // this pair's slices of the batch (all strides are zero for a single pair)
-    A.kpsL += (size_t)pair * A.strideL; A.descL += (size_t)pair * A.strideL * 32;
-    A.kpsR += (size_t)pair * A.strideR; A.descR += (size_t)pair * A.strideR * 32;
-    A.row_start += (size_t)pair * A.row_stride; A.row_items += (size_t)pair * A.items_stride;
-    A.uRight += (size_t)pair * A.strideL; A.depth += (size_t)pair * A.strideL; A.best_sad += (size_t)pair * A.strideL;
+    // this pair's slices of the batch (all strides are zero for a single pair); the argument block itself stays
+    // untouched in constant memory, where its per-level tables are indexed at run time
+    const orbgpu_keypoint *__restrict__ kpsL = A.kpsL + (size_t)pair * A.strideL, *__restrict__ kpsR = A.kpsR + (size_t)pair * A.strideR;
+    const uint8_t *__restrict__ descL = A.descL + (size_t)pair * A.strideL * 32, *__restrict__ descR = A.descR + (size_t)pair * A.strideR * 32;
+    const int32_t *__restrict__ row_start = A.row_start + (size_t)pair * A.row_stride;
+    const int32_t *__restrict__ row_items = A.row_items + (size_t)pair * A.items_stride;
+    const size_t outL = (size_t)pair * A.strideL;
     float out_u = -1.0f, out_d = -1.0f;
     int out_sad = -1;
-    const orbgpu_keypoint kpL = A.kpsL[iL];
+    const orbgpu_keypoint kpL = kpsL[iL];
     const int levelL = min(max(kpL.octave, 0), A.nlevels - 1);  // the host entry point rejects octaves outside the pyramid
     const float vL = kpL.y, uL = kpL.x;
     const int row = (int)vL;
@@ -132,29 +134,28 @@ __global__ __launch_bounds__(256) void k_stereo(StereoArgs A)
     const float minU = __fsub_rn(uL, maxD), maxU = uL;
     do {
         if (row < 0 || row >= A.nRows) break;
-        const int s = A.row_start[row], e = A.row_start[row + 1];
+        const int s = row_start[row], e = row_start[row + 1];
         if (s == e || maxU < 0) break;
         uint32_t qd[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) qd[k] = reinterpret_cast<const uint32_t *>(A.descL)[(size_t)iL * 8 + k];
+        for (int k = 0; k < 8; k++) qd[k] = reinterpret_cast<const uint32_t *>(descL)[(size_t)iL * 8 + k];
         uint32_t best = 0xFFFFFFFFu;
         for (int k = s + lane; k < e; k += 64) {
-            const int iR = A.row_items[k];
-            const orbgpu_keypoint kpR = A.kpsR[iR];
+            const int iR = row_items[k];
+            const orbgpu_keypoint kpR = kpsR[iR];
             if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
             if (!(kpR.x >= minU && kpR.x <= maxU)) continue;
-            const int dist = hamming8(qd, reinterpret_cast<const uint32_t *>(A.descR) + (size_t)iR * 8);
+            const int dist = hamming8(qd, reinterpret_cast<const uint32_t *>(descR) + (size_t)iR * 8);
             if (dist < ORBGPU_TH_HIGH) best = min(best, ((uint32_t)dist << 20) | (uint32_t)(k - s));
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+        best = wave_min_u32(best);
         if (best == 0xFFFFFFFFu) break;
         const int bestDist = (int)(best >> 20);
         if (!(bestDist < (ORBGPU_TH_HIGH + ORBGPU_TH_LOW) / 2)) break;
-        const int bestIdxR = A.row_items[s + (int)(best & 0xFFFFFu)];
+        const int bestIdxR = row_items[s + (int)(best & 0xFFFFFu)];
 
         // sub-pixel refinement by correlation (:686-757)
-        const float uR0 = A.kpsR[bestIdxR].x;
+        const float uR0 = kpsR[bestIdxR].x;
         const float sf = A.inv_scale[levelL];
         const float scaleduL = roundf(__fmul_rn(kpL.x, sf)), scaledvL = roundf(__fmul_rn(kpL.y, sf));
         const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
@@ -178,8 +179,7 @@ __global__ __launch_bounds__(256) void k_stereo(StereoArgs A)
             const int cR = PR[(int64_t)(y0 + w) * sR + xR0 + w];
             int acc = abs(a0 - ((int)PR[(int64_t)(y0 + py0) * sR + xR0 + px0] - cR));
             if (p1 < 121) acc += abs(a1 - ((int)PR[(int64_t)(y0 + py1) * sR + xR0 + px1] - cR));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            acc = wave_sum(acc);
             if (acc < bestSad) { bestSad = acc; bestinc = inc; }
             vd[inc + L] = (float)acc;
         }
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void k_stereo(StereoArgs A)
         }
     } while (0);
     if (lane == 0) {
-        A.uRight[iL] = out_u;
-        A.depth[iL] = out_d;
-        A.best_sad[iL] = out_sad;
+        A.uRight[outL + iL] = out_u;
+        A.depth[outL + iL] = out_d;
+        A.best_sad[outL + iL] = out_sad;
     }
 }
 

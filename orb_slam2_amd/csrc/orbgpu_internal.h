@@ -156,6 +156,21 @@ __device__ __forceinline__ int wave_scan_incl(int v)
     return v;
 }
 
+// Sum and unsigned minimum over the 64 lanes of a wave (all lanes active), the result wave-uniform: the scan above
+// (and its twin with min, whose shifted-in and masked-out lanes read the identity) ends in lane 63.
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_scan_incl(v), 63); }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    const int id = -1;  // 0xFFFFFFFF
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Exclusive scan over the block (blockDim.x a multiple of 64, <= 1024).
 // lds needs 33 ints.  Every thread must call it.
 __device__ __forceinline__ int block_scan_excl(int v, int *total, int *lds)
