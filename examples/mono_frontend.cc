@@ -136,5 +136,42 @@ int main(int argc, char **argv)
     }
     std::sort(tb.begin(), tb.end()); std::sort(ts.begin(), ts.end());
     std::printf("device_frames build_ms %.4f stack_matcher_ms %.4f\n", tb[tb.size() / 2], ts[ts.size() / 2]);
+
+    // The pattern of a Frame constructor: a NEW DeviceFrame per image (make_shared), built, its keypoints fetched, and the
+    // frame before the last one destroyed when its shared_ptr goes -- create and destroy recycle the frame's device block.
+    std::vector<double> tp;
+    for (int it = 0; it < 55; it++) {
+        const clk::time_point t0 = clk::now();
+        MiniFrame &F = fr[it & 1];
+        F.mpDeviceFrame = std::make_shared<ORB_SLAM2::DeviceFrame>(extractor.MaxKeypoints());  // the old one is destroyed here
+        const int N = F.mpDeviceFrame->BuildMono(extractor, im[it & 1].data, w, h, w, K4, D5, bounds);
+        F.mpDeviceFrame->KeysUn(F.mvKeysUn);
+        const clk::time_point t1 = clk::now();
+        if (N != (int)keys[it & 1].size()) { std::fprintf(stderr, "recycled device frame: %d keypoints, operator() %zu\n", N, keys[it & 1].size()); return 1; }
+        if (it >= 5) tp.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+    }
+    std::sort(tp.begin(), tp.end());
+    std::printf("device_frames_per_frame make_build_destroy_ms %.4f\n", tp[tp.size() / 2]);
+
+    // An image larger than the extractor's working set: operator() grows the handle once instead of failing (the
+    // reference accepts any image size).  Checked against an extractor that was created for the larger size.
+    {
+        const int W2 = w + 64, H2 = h + 32;
+        std::vector<uint8_t> big((size_t)W2 * H2);
+        for (int y = 0; y < H2; y++)
+            for (int x = 0; x < W2; x++) big[(size_t)y * W2 + x] = buf[0][(size_t)(y % h) * w + (x % w)];
+        orbcv::Mat imBig(H2, W2, big.data(), (size_t)W2);
+        ORB_SLAM2::ORBextractor sized(1000, 1.2f, 8, 20, 7, 0, W2, H2);
+        std::vector<orbcv::KeyPoint> kGrown, kSized;
+        orbcv::Mat dGrown, dSized;
+        extractor(imBig, nomask, kGrown, dGrown);  // created for w x h
+        sized(imBig, nomask, kSized, dSized);
+        const bool same = !kGrown.empty() && kGrown.size() == kSized.size() &&
+                          std::memcmp(kGrown.data(), kSized.data(), kGrown.size() * sizeof(orbcv::KeyPoint)) == 0 &&
+                          std::memcmp(dGrown.data, dSized.data, kGrown.size() * 32) == 0;
+        extractor(im[0], nomask, keys[0], desc[0]);  // and the original size still works on the grown handle
+        std::printf("grown_handle keypoints %zu equal %d small_again %zu\n", kGrown.size(), same ? 1 : 0, keys[0].size());
+        if (!same) { std::fprintf(stderr, "grown handle: %s\n", extractor.LastError().c_str()); return 1; }
+    }
     return 0;
 }

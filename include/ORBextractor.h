@@ -15,6 +15,11 @@
  * Error behaviour: the reference's operator() is void and never throws; it
  * returns silently on an empty image (src/ORBextractor.cc:1459-1460).  Here a
  * failing GPU call leaves the outputs empty and the reason in LastError().
+ *
+ * Image size: the reference accepts any image.  The device working set is sized
+ * for max_width x max_height; an image beyond it makes operator() build a larger
+ * handle once (tables, buffers and launch graphs for the new size, a few
+ * milliseconds) and go on with that one -- Handle() then returns the new handle.
  */
 #ifndef ORBGPU_ORBEXTRACTOR_H
 #define ORBGPU_ORBEXTRACTOR_H
@@ -102,22 +107,16 @@ public:
     // device working set (defaults cover the shipped TUM/EuRoC/KITTI configs).
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0,
                  int max_width = 1280, int max_height = 720)
-        : nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST), minThFAST(minThFAST)
+        : nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST), minThFAST(minThFAST),
+          device_(device)
     {
-        orbgpu_params p;
-        std::memset(&p, 0, sizeof(p));
-        p.nfeatures = nfeatures; p.scaleFactor = (float)scaleFactor; p.nlevels = nlevels;
-        p.iniThFAST = iniThFAST; p.minThFAST = minThFAST; p.device = device;
-        p.max_width = max_width; p.max_height = max_height; p.max_batch = 1;
-        if (orbgpu_extractor_create(&p, &handle_) != ORBGPU_OK) { handle_ = nullptr; err_ = orbgpu_last_error(); return; }
+        if (!Rebuild(max_width, max_height)) return;
         mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
         mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
         mnFeaturesPerLevel.resize(nlevels);
         int32_t n = 0;
         orbgpu_extractor_tables(handle_, &n, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
                                 mvInvLevelSigma2.data(), mnFeaturesPerLevel.data());
-        orbgpu_extractor_max_keypoints(handle_, &max_kp_);
-        mvImagePyramid.bind(handle_, nlevels);
     }
     ~ORBextractor() { orbgpu_extractor_destroy(handle_); }
     ORBextractor(const ORBextractor &) = delete;
@@ -138,6 +137,11 @@ public:
 #endif
         keypoints.clear();
         if (!handle_) return;
+        // an image larger than the working set: a larger handle, once (the reference takes any size)
+        if ((w > max_w_ || h > max_h_) && !Rebuild(w > max_w_ ? w : max_w_, h > max_h_ ? h : max_h_)) {
+            descriptors.release();
+            return;
+        }
         static_assert(sizeof(orbcv::KeyPoint) == sizeof(orbgpu_keypoint), "KeyPoint layout");
         kp_buf_.resize((size_t)max_kp_);
         desc_buf_.resize((size_t)max_kp_ * 32);
@@ -182,7 +186,27 @@ protected:
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 
 private:
+    // (Re)creates the device handle for images up to max_width x max_height.  The new handle is built before the old
+    // one is released, so a failure (LastError()) leaves the extractor as it was.
+    bool Rebuild(int max_width, int max_height)
+    {
+        orbgpu_params p;
+        std::memset(&p, 0, sizeof(p));
+        p.nfeatures = nfeatures; p.scaleFactor = (float)scaleFactor; p.nlevels = nlevels;
+        p.iniThFAST = iniThFAST; p.minThFAST = minThFAST; p.device = device_;
+        p.max_width = max_width; p.max_height = max_height; p.max_batch = 1;
+        orbgpu_extractor *h = nullptr;
+        if (orbgpu_extractor_create(&p, &h) != ORBGPU_OK) { err_ = orbgpu_last_error(); return false; }
+        if (handle_) orbgpu_extractor_destroy(handle_);
+        handle_ = h;
+        max_w_ = max_width; max_h_ = max_height;
+        orbgpu_extractor_max_keypoints(handle_, &max_kp_);
+        mvImagePyramid.bind(handle_, nlevels);
+        return true;
+    }
+
     orbgpu_extractor *handle_ = nullptr;
+    int device_ = 0, max_w_ = 0, max_h_ = 0;
     int32_t max_kp_ = 0;
     std::vector<orbgpu_keypoint> kp_buf_;
     std::vector<uint8_t> desc_buf_;

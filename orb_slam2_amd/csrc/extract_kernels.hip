@@ -5,6 +5,7 @@
 //   pyr_copy0 -> pyr_resize (levels 1..L-1, dependent chain) -> fast_cells ->
 //   octree -> blur -> describe
 // Reference lines are relative to /root/reference/src/ORB_SLAM2/.
+#include <atomic>
 #include <vector>
 
 #include <stdlib.h>
@@ -1819,7 +1820,7 @@ extern "C" int orbgpu_debug_fast_stamps(unsigned *out, int nwg, int reset)
 #endif
 
 int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
-                int32_t *cell_counts)
+                int32_t *cell_counts, const LaunchTuning &tune)
 {
     // LDS regions for the largest cell: rows of kTP bytes (all offsets multiples of 16)
     int wmax = 0, hmax = 0;
@@ -1843,10 +1844,7 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
     if (queue_off + 2 * qcap > kLdsShare) qcap = (kLdsShare - queue_off) / 2 > 256 ? (kLdsShare - queue_off) / 2 : 256;
     if (qcap > wmax * hmax) qcap = wmax * hmax;
     // test hook: a smaller queue sends ordinary cells down the dense path (tests/test_gpu_extract.py)
-    if (const char *ov = getenv("ORBGPU_FAST_QUEUE_CAP")) {
-        const int v = atoi(ov);
-        if (v >= 1 && v < qcap) qcap = v;
-    }
+    if (tune.fast_queue_cap >= 1 && tune.fast_queue_cap < qcap) qcap = tune.fast_queue_cap;
     const size_t lds = (size_t)queue_off + (size_t)qcap * 2;
     // A batch: one wave per workgroup and runs of cells, so that a CU holds as many independent workgroups as its
     // LDS allows; a few frames: the cells spread over all CUs, two waves on each
@@ -1869,7 +1867,8 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
 }
 
 int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
-                  QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status)
+                  QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status,
+                  const LaunchTuning &tune)
 {
     int maxcap = 0;
     for (int l = 0; l < G.nlevels; l++) maxcap = G.lv[l].node_cap > maxcap ? G.lv[l].node_cap : maxcap;
@@ -1881,9 +1880,7 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several
     const bool batch = nimg * G.nlevels >= 256;
     int threads = !batch ? 1024 : maxcap <= 512 ? 128 : nimg * G.nlevels >= 2048 ? 256 : 512;
-    if (batch) {  // measurement hook
-        if (const char *ov = getenv("ORBGPU_OCT_THREADS")) threads = atoi(ov) == 128 ? 128 : atoi(ov) == 512 ? 512 : 256;
-    }
+    if (batch && tune.oct_threads) threads = tune.oct_threads;  // measurement hook
     const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
     size_t dyn = coff_off + (size_t)(threads + 1) * 4;
     if (batch) {
@@ -1906,14 +1903,21 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
         pts_cap &= ~3;
         if (pts_cap < 256) pts_cap = 0;
         if (pts_cap) dyn = pts_off + (size_t)pts_cap * 8;
-        static size_t granted = 64 * 1024;  // dynamic LDS beyond 64 KiB is asked for once
-        if (dyn > granted) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget + 8192) == hipSuccess) {
-                granted = 160 * 1024;
-            } else {
-                (void)hipGetLastError();
-                pts_cap = 0;
-                dyn = coff_off + (size_t)(threads + 1) * 4;
+        // dynamic LDS beyond 64 KiB is asked for once per device (the attribute belongs to the device's copy of the
+        // kernel); handles on several devices, or the two extractors of a stereo build on two host threads, may get here
+        // at the same time
+        if (dyn > 64 * 1024) {
+            static std::atomic<bool> granted[64];
+            int dev = -1;
+            const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+            if (!(known && granted[dev].load(std::memory_order_acquire))) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget + 8192) == hipSuccess) {
+                    if (known) granted[dev].store(true, std::memory_order_release);
+                } else {
+                    (void)hipGetLastError();
+                    pts_cap = 0;
+                    dyn = coff_off + (size_t)(threads + 1) * 4;
+                }
             }
         }
         hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch, sel,

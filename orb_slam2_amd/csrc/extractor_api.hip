@@ -32,9 +32,10 @@ int launch_halo_full(hipStream_t st, int nimg, uint8_t *pyr, const Geom &G);
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
                    const Geom &G, const XTab *xtab, const YTab *ytab, const FuseArgs *fuse);
 int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
-                int32_t *cell_counts);
+                int32_t *cell_counts, const LaunchTuning &tune);
 int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
-                  QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status);
+                  QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status,
+                  const LaunchTuning &tune);
 int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G, const uint32_t *tile_tab, int ntiles);
 int blur_tile_table(const Geom &G, std::vector<uint32_t> *tab);
 int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t *blur, const Geom &G, const uint32_t *sel,
@@ -154,6 +155,7 @@ using namespace orbgpu;
 
 struct orbgpu_extractor {
     orbgpu_params p;
+    LaunchTuning tune;  // environment hooks, read once in orbgpu_extractor_create
     float scale[ORBGPU_MAX_LEVELS], inv_scale[ORBGPU_MAX_LEVELS], sigma2[ORBGPU_MAX_LEVELS], inv_sigma2[ORBGPU_MAX_LEVELS];
     int32_t quota[ORBGPU_MAX_LEVELS];
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -576,6 +578,8 @@ int orbgpu_extractor_create(const orbgpu_params *p, orbgpu_extractor **out)
     orbgpu_extractor *e = new (std::nothrow) orbgpu_extractor();
     if (!e) return ORBGPU_E_NOMEM;
     e->p = *p;
+    if (const char *ov = getenv("ORBGPU_FAST_QUEUE_CAP")) e->tune.fast_queue_cap = atoi(ov) > 0 ? atoi(ov) : 0;
+    if (const char *ov = getenv("ORBGPU_OCT_THREADS")) e->tune.oct_threads = atoi(ov) == 128 ? 128 : atoi(ov) == 512 ? 512 : atoi(ov) == 256 ? 256 : 0;
     compute_tables(e);
     int rc = ORBGPU_OK;
     do {
@@ -783,7 +787,7 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, pyr, G, (const XTab *)e->xtab.p, (const YTab *)e->ytab.p, &e->fuse)))
         return rc;
     STAGE_MARK(1);
-    if ((rc = launch_fast(st, nimg, pyr, G, (const uint32_t *)e->cell_tab.p, slots, cell_counts))) return rc;
+    if ((rc = launch_fast(st, nimg, pyr, G, (const uint32_t *)e->cell_tab.p, slots, cell_counts, e->tune))) return rc;
     STAGE_MARK(2);
     // fork: the blur depends on the pyramid only.  FAST keeps every SIMD busy, the
     // quadtree is latency-bound, so the blur is released after FAST to run beside the quadtree.  For one or two
@@ -798,7 +802,7 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     if ((rc = launch_blur(ax, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
     if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
     if (!serial) ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
-    if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status)))
+    if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune)))
         return rc;
     STAGE_MARK(3);
     if (!serial) ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,26 @@ __global__ __launch_bounds__(256) void k_frame_finish(const orbgpu_keypoint *__r
 }  // namespace orbgpu
 
 using namespace orbgpu;
+
+// Frame blocks are recycled like matcher contexts: the reference constructs a Frame per image (src/Tracking.cc:240, 270,
+// 330) and destroys the one before the last, so create / destroy must not go to the allocator (hipMalloc, hipFree and
+// the device-wide waits they imply would stall every other stream of the process once per frame).
+// orbgpu_frame_destroy parks an idle frame of the same device here, orbgpu_frame_create takes one of the wanted
+// capacity back.
+static std::mutex g_frame_pool_mutex;
+static std::vector<orbgpu_frame *> g_frame_pool[64];
+static const size_t kFramePoolPerDevice = 16;
+
+// A build that fails after its extraction was enqueued must not return while the extractor's streams still run: the
+// next call on those handles rewrites their staging and output blocks at once.
+static int fail_after_enqueue(int rc, const HostExtraction *XL, const HostExtraction *XR)
+{
+    if (rc != ORBGPU_OK) {
+        if (XL && XL->stream) (void)hipStreamSynchronize(XL->stream);
+        if (XR && XR->stream) (void)hipStreamSynchronize(XR->stream);
+    }
+    return rc;
+}
 
 static int frame_check(const char *who, orbgpu_frame *f, const float *K4, const float *dist5, const float *bounds4, int32_t *n_out)
 {
@@ -153,6 +174,10 @@ static int frame_complete(orbgpu_frame *f, const HostExtraction &X, const HostEx
     return ORBGPU_OK;
 }
 
+static int frame_stereo_enqueue(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_extractor *right, const HostExtraction &XL,
+                                const HostExtraction &XR, StereoArgs &S, int32_t w, int32_t h, float bf, float b, const float *K4,
+                                const float *dist5);
+
 static int frame_begin(orbgpu_frame *f, orbgpu_extractor *e, const float *bounds4)
 {
     ORBGPU_HIP_CHECK(hipSetDevice(f->device));
@@ -176,6 +201,16 @@ int orbgpu_frame_create(int32_t device, int32_t capacity, orbgpu_frame **out)
     }
     *out = nullptr;
     ORBGPU_HIP_CHECK(hipSetDevice(device));
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lock(g_frame_pool_mutex);
+        std::vector<orbgpu_frame *> &pool = g_frame_pool[device];
+        for (size_t i = 0; i < pool.size(); i++)
+            if (pool[i]->capacity == capacity) {
+                *out = pool[i];
+                pool.erase(pool.begin() + (long)i);
+                return ORBGPU_OK;
+            }
+    }
     orbgpu_frame *f = new (std::nothrow) orbgpu_frame;
     if (!f) return ORBGPU_E_NOMEM;
     f->device = device;
@@ -208,11 +243,23 @@ int orbgpu_frame_create(int32_t device, int32_t capacity, orbgpu_frame **out)
     return ORBGPU_OK;
 }
 
+// Nothing of the library reads a frame after the call that was given it has returned (the build calls and the *_frame
+// searches wait for their stream), so there is nothing to wait for here; a caller that runs kernels of its own on
+// the views of orbgpu_frame_device finishes them first.
 void orbgpu_frame_destroy(orbgpu_frame *f)
 {
     if (!f) return;
+    if (f->device >= 0 && f->device < 64) {
+        f->built = false;
+        f->h_valid = false;
+        f->n = f->nvalid = 0;
+        std::lock_guard<std::mutex> lock(g_frame_pool_mutex);
+        if (g_frame_pool[f->device].size() < kFramePoolPerDevice) {
+            g_frame_pool[f->device].push_back(f);
+            return;
+        }
+    }
     (void)hipSetDevice(f->device);
-    (void)hipDeviceSynchronize();  // matcher calls that read the frame may still be in flight
     f->worker.stop();
     if (f->ev) (void)hipEventDestroy(f->ev);
     if (f->stereo_block) (void)hipFree(f->stereo_block);
@@ -229,8 +276,8 @@ int orbgpu_frame_build_mono(orbgpu_frame *f, orbgpu_extractor *e, const uint8_t 
     HostExtraction X;
     const uint8_t *one[1] = {img};
     if ((rc = extract_host_begin(e, one, 1, w, h, stride, &X))) return rc;
-    if ((rc = frame_finish_enqueue(f, X, K4, dist5, 0, nullptr, w, h, 0.0f))) return rc;
-    if ((rc = frame_grid_enqueue(f, X.stream))) return rc;
+    if ((rc = frame_finish_enqueue(f, X, K4, dist5, 0, nullptr, w, h, 0.0f))) return fail_after_enqueue(rc, &X, nullptr);
+    if ((rc = frame_grid_enqueue(f, X.stream))) return fail_after_enqueue(rc, &X, nullptr);
     return frame_complete(f, X, nullptr, false, n_out);
 }
 
@@ -249,10 +296,13 @@ int orbgpu_frame_build_rgbd(orbgpu_frame *f, orbgpu_extractor *e, const uint8_t 
     HostExtraction X;
     const uint8_t *one[1] = {img};
     if ((rc = extract_host_begin(e, one, 1, w, h, stride, &X))) return rc;
-    ORBGPU_HIP_CHECK(hipMemcpy2DAsync(f->stereo_block, (size_t)w * 4, depth, (size_t)depth_stride_floats * 4, (size_t)w * 4, (size_t)h,
-                                      hipMemcpyHostToDevice, X.stream));
-    if ((rc = frame_finish_enqueue(f, X, K4, dist5, 1, (const float *)f->stereo_block, w, h, bf))) return rc;
-    if ((rc = frame_grid_enqueue(f, X.stream))) return rc;
+    if (hipMemcpy2DAsync(f->stereo_block, (size_t)w * 4, depth, (size_t)depth_stride_floats * 4, (size_t)w * 4, (size_t)h,
+                         hipMemcpyHostToDevice, X.stream) != hipSuccess) {
+        set_error("orbgpu_frame_build_rgbd: the upload of the depth image failed");
+        return fail_after_enqueue(ORBGPU_E_HIP, &X, nullptr);
+    }
+    if ((rc = frame_finish_enqueue(f, X, K4, dist5, 1, (const float *)f->stereo_block, w, h, bf))) return fail_after_enqueue(rc, &X, nullptr);
+    if ((rc = frame_grid_enqueue(f, X.stream))) return fail_after_enqueue(rc, &X, nullptr);
     return frame_complete(f, X, nullptr, true, n_out);
 }
 
@@ -283,6 +333,7 @@ int orbgpu_frame_build_stereo(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_ex
     }
     // the two extractions run side by side on the two handles' streams (two threads in the reference, :78-81)
     HostExtraction XL, XR;
+    XL.stream = XR.stream = nullptr;
     const uint8_t *oneL[1] = {imgL}, *oneR[1] = {imgR};
     // the right image is staged and enqueued by the handle's helper thread while this one does the left image
     int rcR = ORBGPU_OK;
@@ -294,11 +345,27 @@ int orbgpu_frame_build_stereo(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_ex
     });
     rc = extract_host_begin(left, oneL, 1, w, h, stride, &XL);
     f->worker.wait();
-    if (rc) return rc;
+    if (rc) return fail_after_enqueue(rc, nullptr, rcR ? nullptr : &XR);  // the right image may be in flight
     if (rcR) {
         set_error("right image: %s", errR.c_str());
-        return rcR;
+        return fail_after_enqueue(rcR, &XL, nullptr);
     }
+    rc = frame_stereo_enqueue(f, left, right, XL, XR, S, w, h, bf, b, K4, dist5);
+    if (rc) return fail_after_enqueue(rc, &XL, &XR);
+    if ((rc = frame_complete(f, XL, &XR, true, n_out))) return rc;
+    if (nvalid_out) *nvalid_out = f->nvalid;
+    return ORBGPU_OK;
+}
+
+}  // extern "C"
+
+// The part of the stereo build behind the two extractions: join the right extractor's stream, row table, matching,
+// outlier cut, grid -- all enqueued on the left extractor's stream.
+static int frame_stereo_enqueue(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_extractor *right, const HostExtraction &XL,
+                                const HostExtraction &XR, StereoArgs &S, int32_t w, int32_t h, float bf, float b, const float *K4,
+                                const float *dist5)
+{
+    int rc;
     hipStream_t st = XL.stream;
     if (XR.stream != st) {
         ORBGPU_HIP_CHECK(hipEventRecord(f->ev, XR.stream));
@@ -329,11 +396,10 @@ int orbgpu_frame_build_stereo(orbgpu_frame *f, orbgpu_extractor *left, orbgpu_ex
     S.uRight = f->uright; S.depth = f->depth; S.best_sad = best_sad;
     if ((rc = launch_stereo(st, S))) return rc;
     if ((rc = launch_stereo_outliers(st, best_sad, f->count, f->capacity, f->uright, f->depth, f->count + 1))) return rc;
-    if ((rc = frame_grid_enqueue(f, st))) return rc;
-    if ((rc = frame_complete(f, XL, &XR, true, n_out))) return rc;
-    if (nvalid_out) *nvalid_out = f->nvalid;
-    return ORBGPU_OK;
+    return frame_grid_enqueue(f, st);
 }
+
+extern "C" {
 
 // A frame from host arrays (a Frame the program computed itself, a KeyFrame read back from a saved map): the
 // arrays are uploaded and the grid is built as AssignFeaturesToGrid does.

@@ -58,6 +58,12 @@ def test_cpp_driver_matches_python(tmp_path):
     total = 0.0
     for w in sorted(bow):
         total += bow[w]
+    # operator() on an image larger than the handle's working set grows the handle (checked inside the driver against an
+    # extractor created for that size) and the original size still extracts the same keypoints afterwards
+    grown = [l.split() for l in out.stdout.splitlines() if l.startswith("grown_handle")]
+    assert grown and grown[0][4] == "1" and int(grown[0][2]) > 500 and int(grown[0][6]) == len(k0)
+    per_frame = [l.split() for l in out.stdout.splitlines() if l.startswith("device_frames_per_frame")]
+    assert per_frame and float(per_frame[0][2]) < 5.0  # a recycled frame block: no allocation per frame
     t2 = out.stdout.splitlines()[1].split()
     assert t2[0] == "words" and int(t2[1]) == v.size() and int(t2[3]) == len(bow)
     assert float(t2[5]) == total and int(t2[7]) == len(fv) and int(t2[11]) == fsum

@@ -529,7 +529,7 @@ def test_quadtree_tie_rule_is_locked(oracle):
 def test_fast_dense_path_when_the_survivor_queue_overflows(oracle, monkeypatch):
     """The FAST kernel's survivor queue is bounded (so that a CU holds 32 of its workgroups); a cell with more
     survivors is evaluated densely, every pixel of it.  With the queue capped at 24 entries (ORBGPU_FAST_QUEUE_CAP, a
-    test hook read at every launch) nearly every cell takes that path, in the two-wave single-frame kernel and in
+    test hook read when a handle is created) nearly every cell takes that path, in the two-wave single-frame kernel and in
     the one-wave batch kernel: candidates (order included) and the extraction equal the oracle's, noise included."""
     monkeypatch.setenv("ORBGPU_FAST_QUEUE_CAP", "24")
     rng = np.random.default_rng(3)
