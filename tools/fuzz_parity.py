@@ -76,7 +76,7 @@ def compare_extract(ex, oe, img, stats):
     stats["frames"] += 1
     stats["tie_levels"] += ties
     stats["tie_frames"] += 1 if ties else 0
-    if ties and stats["frames"] % 4 == 0:
+    if stats["frames"] % 4 == 0:  # sampled whether or not a tie straddles the cut: the order alone can change too
         O.set_tie_rule(1)
         try:
             akps, _ = oe.extract(img)
@@ -86,6 +86,16 @@ def compare_extract(ex, oe, img, stats):
         other = set(zip(akps["x"].tolist(), akps["y"].tolist(), akps["octave"].tolist()))
         stats["tie_sampled_kp"] += len(mine)
         stats["tie_dependent_kp"] += len(mine - other)
+        # per level: does the other tie order select another set, or the same set in another output order (the
+        # windowed matchers resolve their claims in keypoint order, so the order is an output too)
+        for lv in np.union1d(okps["octave"], akps["octave"]):
+            a = [(x, y) for x, y in zip(okps["x"][okps["octave"] == lv].tolist(), okps["y"][okps["octave"] == lv].tolist())]
+            b = [(x, y) for x, y in zip(akps["x"][akps["octave"] == lv].tolist(), akps["y"][akps["octave"] == lv].tolist())]
+            stats["tie_levels_sampled"] += 1
+            if set(a) != set(b):
+                stats["tie_levels_set_differs"] += 1
+            elif a != b:
+                stats["tie_levels_order_only"] += 1
     return None, (okps, odesc)
 
 
@@ -320,7 +330,7 @@ def main(argv=None, stats_out=None):
     args = ap.parse_args(argv)
     O.build()
     stats = dict(angle_max_deg=0.0, angle_inexact=0, desc_diff=0, desc_total=0, kp_total=0, frames=0, tie_levels=0, tie_frames=0,
-                 tie_sampled_kp=0, tie_dependent_kp=0)
+                 tie_sampled_kp=0, tie_dependent_kp=0, tie_levels_sampled=0, tie_levels_set_differs=0, tie_levels_order_only=0)
     t_end = time.time() + args.seconds
     case, nfail, nskip, nmatch = 0, 0, 0, 0
     m = api.ORBmatcher(0.9, True)
@@ -396,6 +406,8 @@ def main(argv=None, stats_out=None):
     print("quadtree size ties straddling the cut (the reference orders them by heap address): %d of %d frames, %d levels; "
           "keypoints that change with the tie order (earliest- instead of latest-created node first, sampled): %d of %d"
           % (stats["tie_frames"], stats["frames"], stats["tie_levels"], stats["tie_dependent_kp"], stats["tie_sampled_kp"]), flush=True)
+    print("levels sampled with both tie orders: %d; another keypoint set on %d, the same set in another output order on %d"
+          % (stats["tie_levels_sampled"], stats["tie_levels_set_differs"], stats["tie_levels_order_only"]), flush=True)
     if stats_out is not None:
         stats_out.update(stats)
     return 1 if nfail else 0
