@@ -806,42 +806,62 @@ def cfg_euroc_search(torch, dev, B):
     return out
 
 
+class SplitExtractor:
+    """n frames per call, split over `nsplit` extractor handles on their own streams (contiguous shares): for small
+    batches of large images the latency-bound quadtree of one share then overlaps the FAST / blur kernels of another."""
+
+    def __init__(self, torch, dev, api, nfeat, w, h, n, nsplit, device=0):
+        self.torch, self.dev, self.w, self.h = torch, dev, w, h
+        self.shares = [(i * n // nsplit, (i + 1) * n // nsplit) for i in range(nsplit)]
+        self.shares = [(a, b) for a, b in self.shares if b > a]
+        self.exs = [api.ORBextractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, device=device, max_width=w, max_height=h, max_batch=b - a)
+                    for a, b in self.shares]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.shares]
+        for e, st in zip(self.exs, self.streams):
+            e.set_stream(st.cuda_stream)
+        self.cap = self.exs[0].max_keypoints
+
+    def __call__(self, d_imgs, d_k, d_d, d_c):
+        for (a, b), e in zip(self.shares, self.exs):
+            e.extract_batch_device(d_imgs[a].data_ptr(), b - a, self.w, self.h, self.w, self.w * self.h, d_k[a].data_ptr(), d_d[a].data_ptr(),
+                                   self.cap, d_c[a:].data_ptr())
+
+
 def cfg_4k(torch, dev, total, launches):
     """`total` frames of 3840x2160 with 8000 features, extraction only, device-resident (4 distinct frames cycled), at
-    several numbers of frames per launch (a rank's share at 8 ranks is 32)."""
+    several (frames per call, handles the call is split over): a rank's share at 8 ranks is 32 frames."""
     from oracle import oracle as O
     from orb_slam2_amd import api, synth
     w, h, nfeat = 3840, 2160, 8000
     distinct = synth.sequence(w, h, 4, seed=4, n_shapes=(w * h) // 768, smax=80)
     d_imgs = torch.from_numpy(distinct).to(dev)[torch.arange(total, device=dev) % 4].contiguous()
-    out = {"workload": "%d frames 3840x2160, 8000 features, 8 levels: extraction, device-resident" % total, "frames_per_launch": {}}
+    out = {"workload": "%d frames 3840x2160, 8000 features, 8 levels: extraction, device-resident" % total, "frames_per_call": {}}
     best = None
-    for per_launch in launches:
+    for per_launch, nsplit in launches:
         n = min(per_launch, total)
-        ex = api.ORBextractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, max_width=w, max_height=h, max_batch=n)
-        cap = ex.max_keypoints
+        sx = SplitExtractor(torch, dev, api, nfeat, w, h, n, nsplit)
+        cap = sx.cap
         d_k = torch.zeros((n, cap, 28), dtype=torch.uint8, device=dev); d_d = torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev)
         d_c = torch.zeros(n, dtype=torch.int32, device=dev)
-        ex.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-
-        def step():
-            ex.extract_batch_device(d_imgs[0].data_ptr(), n, w, h, w, w * h, d_k.data_ptr(), d_d.data_ptr(), cap, d_c.data_ptr())
-        dt = gpu_timed(torch, dev, step, max(2, min(8, 256 // n)))
+        dt = gpu_timed(torch, dev, lambda: sx(d_imgs, d_k, d_d, d_c), max(3, min(8, 256 // n)))
         kp_mean = float(d_c.float().mean().item())
         alg = frame_algorithmic_bytes(w, h, kp_mean)
-        ex.profile(2); step(); iso_ms, _ = ex.stage_times(); ex.profile(False)
-        r = {"frames_per_s": n / dt, "ms_per_launch": dt * 1e3, "keypoints_per_frame": kp_mean,
-             "stages_ms_isolated": {nm: float(v) for nm, v in zip(["pyramid", "fast_cells", "octree", "blur", "describe"], iso_ms)},
+        r = {"frames_per_s": n / dt, "ms_per_call": dt * 1e3, "keypoints_per_frame": kp_mean,
              "roofline": {"bound": "hbm", "achieved": alg * n / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg * n / dt / 1e9 / HBM_PEAK_GBS,
                           "algorithmic_bytes_per_frame": alg}}
-        out["frames_per_launch"][str(n)] = r
+        if nsplit == 1:
+            ex = sx.exs[0]
+            ex.profile(2); sx(d_imgs, d_k, d_d, d_c); iso_ms, _ = ex.stage_times(); ex.profile(False)
+            r["stages_ms_isolated"] = {nm: float(v) for nm, v in zip(["pyramid", "fast_cells", "octree", "blur", "describe"], iso_ms)}
+        out["frames_per_call"]["%d frames, %d handle%s" % (n, len(sx.shares), "" if len(sx.shares) == 1 else "s on their own streams")] = r
         if best is None or r["frames_per_s"] > best["frames_per_s"]:
             best = r
-        if per_launch == launches[-1]:
+        if (per_launch, nsplit) == launches[-1]:
             # parity + CPU leg: frame 0 through the oracle (one 4K extraction on one host core)
             t0 = time.perf_counter()
             ok_k, ok_d = O.Extractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH).extract(distinct[0])
             t_cpu = time.perf_counter() - t0
+            torch.cuda.synchronize(dev)
             c0 = int(d_c[0].item())
             kg = d_k[0].cpu().numpy().view(api.KEYPOINT_DTYPE).reshape(-1)[:c0]; dg = d_d[0].cpu().numpy()[:c0]
             bad = compare_extraction(kg, dg, ok_k.view(api.KEYPOINT_DTYPE), ok_d)
@@ -849,7 +869,7 @@ def cfg_4k(torch, dev, total, launches):
             out["parity_in_run"] = {"frames": 1, "mismatches": int(bool(bad) or ndiff > 0.001 * max(c0, 1)), "keypoints_compared": c0,
                                     "descriptors_differing": ndiff, "detail": bad}
             out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "one frame, one thread, %.2f s" % t_cpu}
-        del ex, d_k, d_d, d_c
+        del sx, d_k, d_d, d_c
     out["frames_per_s"] = best["frames_per_s"]
     out["roofline"] = best["roofline"]
     return out
@@ -899,7 +919,7 @@ def run_configs(args, torch, dev, with_cpu):
             ("euroc_stereo", lambda: cfg_stereo(torch, dev, "EuRoC 752x480 stereo, 1200 features per eye: two extractions + ComputeStereoMatches",
                                                 752, 480, 1200, 47.90639384423901, 435.2046959714599, 3, args.stereo_batch, with_cpu)),
             ("euroc_search_by_projection", lambda: cfg_euroc_search(torch, dev, args.stereo_batch)),
-            ("batch_4k", lambda: cfg_4k(torch, dev, args.frames_4k, [args.frames_4k, 32])),
+            ("batch_4k", lambda: cfg_4k(torch, dev, args.frames_4k, [(args.frames_4k, 1), (32, 1), (32, 2), (32, 4)])),
             ("bruteforce_100k", lambda: cfg_bruteforce(torch, dev, 100000))]
     for name, fn in todo:
         t0 = time.perf_counter()
@@ -924,20 +944,24 @@ def run_4k(args, rank, local_rank, world, torch, dev, barrier):
     idx = torch.tensor([g % 4 for g in mine], dtype=torch.long)
     d_imgs = torch.from_numpy(distinct).to(dev)[idx.to(dev)].contiguous()
     per_launch = min(n, args.launch_4k)
-    ex = api.ORBextractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=w, max_height=h, max_batch=per_launch)
-    cap = ex.max_keypoints
+    # a small share (a rank's 32 frames at 8 ranks) is split over two handles on their own streams: the quadtree of one
+    # half then runs beside the other half's FAST and blur instead of leaving the chip idle
+    nsplit = args.split_4k if args.split_4k > 0 else (2 if per_launch <= 64 else 1)
+    sx = SplitExtractor(torch, dev, api, nfeat, w, h, per_launch, nsplit, device=local_rank)
+    ex, cap = sx.exs[0], sx.cap
     d_k = torch.zeros((n, cap, 28), dtype=torch.uint8, device=dev)
     d_d = torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev)
     d_c = torch.zeros(n, dtype=torch.int32, device=dev)
 
     def step():
         for lo in range(0, n, per_launch):
-            m = min(per_launch, n - lo)
-            ex.extract_batch_device(d_imgs[lo].data_ptr(), m, w, h, w, w * h, d_k[lo].data_ptr(), d_d[lo].data_ptr(), cap,
-                                    d_c[lo:].data_ptr())
+            if lo + per_launch <= n:
+                sx(d_imgs[lo:], d_k[lo:], d_d[lo:], d_c[lo:])
+            else:  # a last, shorter launch goes through the first handle
+                ex.extract_batch_device(d_imgs[lo].data_ptr(), n - lo, w, h, w, w * h, d_k[lo].data_ptr(), d_d[lo].data_ptr(), cap,
+                                        d_c[lo:].data_ptr())
 
     def sync():
-        ex.sync()
         torch.cuda.synchronize(dev)
 
     wall = timed_steps(step, args.steps, args.warmup, sync, barrier)
@@ -955,14 +979,15 @@ def run_4k(args, rank, local_rank, world, torch, dev, barrier):
     names = ["pyramid", "fast_cells", "octree", "blur", "describe"]
     dom = 1 + int(np.argmax(iso_ms[1:]))
     alg = {"fast_cells": P, "octree": 4 * 32000, "blur": 2 * P, "describe": int(kp_mean * 60)}[names[dom]]
-    m_last = n - (n - 1) // per_launch * per_launch  # frames of the launch the isolated pass timed last
+    m_last = sx.shares[0][1] - sx.shares[0][0] if n % per_launch == 0 else n % per_launch  # frames of the first handle's last launch
     achieved = alg * m_last / (float(iso_ms[dom]) * 1e-3) / 1e9
     return bench_line(
         "frames/sec ORB extract at 3840x2160/8000 kp", "frames/s", total * args.steps / wall_max, world, args.steps, args.warmup,
         wall_max, "strong", "u8", "synthetic (4 distinct frames cycled)",
         {"workload": "256-frame batch 3840x2160, 8000 features, 8 levels: extraction, device-resident, frames sharded in contiguous "
                      "chunks across the ranks",
-         "frames_total": total, "frames_this_rank": n, "frames_per_launch": per_launch, "keypoints_per_frame": kp_mean,
+         "frames_total": total, "frames_this_rank": n, "frames_per_launch": per_launch, "handles_per_launch": len(sx.shares),
+         "keypoints_per_frame": kp_mean,
          "parallelism": "%d rank(s), no collective; ranks lined up over %s" % (world, BACKEND["name"] or "nothing (one process)")},
         roofline={"bound": "hbm", "kernel": KERNEL_OF_STAGE[names[dom]], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms_isolated": float(iso_ms[dom]),
@@ -982,6 +1007,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="tum: independent sub-pipelines (HIP streams) a sub-batch is split over")
     ap.add_argument("--frames-4k", type=int, default=256, help="4k: frames of the whole job per step")
     ap.add_argument("--launch-4k", type=int, default=256, help="4k: frames per launch (at most the rank's share)")
+    ap.add_argument("--split-4k", type=int, default=0, help="4k: handles / streams a launch is split over (0: two for shares of at most 64 frames)")
     ap.add_argument("--stereo-batch", type=int, default=256, help="configs block: stereo pairs / frame pairs per launch")
     ap.add_argument("--no-latency", action="store_true", help="skip the host-side latency / PCIe probes (profiling runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (and with it the in-run parity check of the main workload)")

@@ -98,9 +98,10 @@ int orbgpu_extractor_status(orbgpu_extractor *e, int32_t *flags);
  * orbgpu_extractor_stage_times synchronises and returns the mean milliseconds
  * of {pyramid, FAST cells, quadtree, blur, describe} over the calls since
  * profiling was enabled (at most the last 128).  enable = 1 times the normal
- * schedule (the blur runs on a side stream beside the quadtree, so those two
- * intervals overlap); enable = 2 keeps the blur on the main stream so that
- * every stage is timed alone; 0 switches timing off. */
+ * schedule (the quadtree runs on a stream of its own beside the
+ * blur, so those two intervals overlap and describe's includes the wait for the
+ * quadtree); enable = 2 keeps everything on the main stream so that every stage
+ * is timed alone; 0 switches timing off. */
 int orbgpu_extractor_profile(orbgpu_extractor *e, int32_t enable);
 int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms5, int32_t *ncalls);
 

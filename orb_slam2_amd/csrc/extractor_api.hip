@@ -159,7 +159,7 @@ struct orbgpu_extractor {
     float scale[ORBGPU_MAX_LEVELS], inv_scale[ORBGPU_MAX_LEVELS], sigma2[ORBGPU_MAX_LEVELS], inv_sigma2[ORBGPU_MAX_LEVELS];
     int32_t quota[ORBGPU_MAX_LEVELS];
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t aux_stream = nullptr;          // the blur runs here, beside FAST + quadtree
+    hipStream_t aux_stream = nullptr;          // the quadtree runs here, beside the blur on the main stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     Geom G;
     int geom_w = 0, geom_h = 0;
@@ -188,12 +188,14 @@ struct orbgpu_extractor {
     CopyPool *pool = nullptr;
     // optional stage timing: a ring of event sets, one set per extract call
     bool profile = false;
-    bool serialize = false;  // profiling mode 2: the blur stays on the main stream so every stage is timed alone
+    bool serialize = false;  // profiling mode 2: the quadtree stays on the main stream so every stage is timed alone
+    int last_schedule = 0;  // the last call: 0 = blur, quadtree one after the other on the main stream; 1 = quadtree, 2 = blur on the second stream
     std::vector<hipEvent_t> ev;  // kProfSets * kProfEvents
     int prof_next = 0, prof_used = 0;
 };
 
-static constexpr int kProfSets = 128, kProfEvents = 7;  // start, pyramid, fast, octree, describe | blur start, blur end (aux stream)
+// start, pyramid, fast, blur (octree when serial), describe | second stage start, end: the quadtree on its own stream, or (serial) the blur
+static constexpr int kProfSets = 128, kProfEvents = 7;
 
 // ORBextractor::ORBextractor tables (src/ORBextractor.cc:469-512).
 static void compute_tables(orbgpu_extractor *e)
@@ -579,6 +581,7 @@ int orbgpu_extractor_create(const orbgpu_params *p, orbgpu_extractor **out)
     if (!e) return ORBGPU_E_NOMEM;
     e->p = *p;
     if (const char *ov = getenv("ORBGPU_FAST_QUEUE_CAP")) e->tune.fast_queue_cap = atoi(ov) > 0 ? atoi(ov) : 0;
+    if (const char *ov = getenv("ORBGPU_SCHEDULE")) e->tune.schedule = atoi(ov) == 1 ? 1 : atoi(ov) == 2 ? 2 : 0;
     if (const char *ov = getenv("ORBGPU_OCT_THREADS")) e->tune.oct_threads = atoi(ov) == 128 ? 128 : atoi(ov) == 512 ? 512 : atoi(ov) == 256 ? 256 : 0;
     compute_tables(e);
     int rc = ORBGPU_OK;
@@ -586,6 +589,9 @@ int orbgpu_extractor_create(const orbgpu_params *p, orbgpu_extractor **out)
         if (hipSetDevice(p->device) != hipSuccess) { set_error("hipSetDevice failed"); rc = ORBGPU_E_HIP; break; }
         if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = ORBGPU_E_HIP; break; }
         e->stream = e->own_stream;
+        // An ordinary stream: created with the highest stream priority (so that the quadtree's few long workgroups are
+        // placed ahead of the throughput kernels), the chunked host path, which has four streams and several calls in
+        // flight, stopped making progress on this runtime.
         if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { set_error("aux stream/event creation failed"); rc = ORBGPU_E_HIP; break; }
@@ -668,9 +674,12 @@ int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms5, int32_t *ncall
     if (!e || !ms5) return ORBGPU_E_INVALID;
     ORBGPU_HIP_CHECK(hipSetDevice(e->p.device));
     ORBGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
-    // {pyramid, fast, octree, blur (aux stream), describe (includes waiting for the blur)}
-    // serialized mode: the blur sits between FAST and the quadtree on the one stream
-    const int from[5] = {0, 1, e->serialize ? 6 : 2, 5, 3}, to[5] = {1, 2, 3, 6, 4};
+    // {pyramid, fast, octree, blur, describe}.  Two streams: the quadtree runs on its own stream (events 5 -> 6) beside
+    // the blur on the main stream (2 -> 3), and describe's interval (3 -> 4) includes waiting for the quadtree.
+    // One stream (serialized mode, one or two frames): FAST, blur (5 -> 6), quadtree (6 -> 3), describe.
+    // The blur on the second stream instead: blur 5 -> 6, quadtree 2 -> 3.
+    const int sch = e->last_schedule;
+    const int from[5] = {0, 1, sch == 0 ? 6 : sch == 1 ? 5 : 2, sch == 1 ? 2 : 5, 3}, to[5] = {1, 2, sch == 1 ? 6 : 3, sch == 1 ? 3 : 6, 4};
     for (int i = 0; i < 5; i++) ms5[i] = 0.f;
     for (int s = 0; s < e->prof_used; s++)
         for (int i = 0; i < 5; i++) {
@@ -789,23 +798,54 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     STAGE_MARK(1);
     if ((rc = launch_fast(st, nimg, pyr, G, (const uint32_t *)e->cell_tab.p, slots, cell_counts, e->tune))) return rc;
     STAGE_MARK(2);
-    // fork: the blur depends on the pyramid only.  FAST keeps every SIMD busy, the
-    // quadtree is latency-bound, so the blur is released after FAST to run beside the quadtree.  For one or two
-    // frames the blur is a few microseconds and handing work to a second queue and back costs more than that.
+    // fork: the blur depends on the pyramid only, the quadtree on FAST.  The quadtree is a few long, latency-bound
+    // workgroups, the blur keeps every SIMD busy: the quadtree goes first, onto a stream of its own, and the blur
+    // fills the chip around it on the main stream.  For one or two frames the blur is a few
+    // microseconds and handing work to a second queue and back costs more than that.
     const bool serial = e->serialize || nimg <= 2;
-    hipStream_t ax = serial ? st : e->aux_stream;
-    if (!serial) {
+
+    // Which of the two goes to the second stream, measured both ways on one GPU: with levels of a few hundred
+    // features (640x480 at 1000 features, 512 frames per launch) the quadtree enqueued first on the second stream gives
+    // the step 270 k frames/s against 267 k; with levels of thousands (3840x2160 at 8000) the blur enqueued first on
+    // the second stream gives 32-frame launches 12.4 k frames/s against 11.7 k, 256-frame launches 14.7 k against 14.2 k.
+    int maxcap = 0;
+    for (int l = 0; l < G.nlevels; l++) maxcap = G.lv[l].node_cap > maxcap ? G.lv[l].node_cap : maxcap;
+    const bool blur_second = e->tune.schedule == 1 || (e->tune.schedule == 0 && maxcap > 512);
+    e->last_schedule = serial ? 0 : blur_second ? 2 : 1;
+    if (serial) {
+        if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], st));
+        if ((rc = launch_blur(st, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
+        if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], st));
+        if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune)))
+            return rc;
+        STAGE_MARK(3);
+    } else if (blur_second) {
+        // the blur on the second stream, enqueued ahead of the quadtree on the main stream (the event intervals then
+        // read: "octree" = the blur's, "blur" = the quadtree's)
+        hipStream_t ax = e->aux_stream;
         ORBGPU_HIP_CHECK(hipEventRecord(e->ev_fork, st));
         ORBGPU_HIP_CHECK(hipStreamWaitEvent(ax, e->ev_fork, 0));
+        if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], ax));
+        if ((rc = launch_blur(ax, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
+        if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
+        ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
+        if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune)))
+            return rc;
+        STAGE_MARK(3);
+        ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
+    } else {
+        hipStream_t ax = e->aux_stream;
+        ORBGPU_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+        ORBGPU_HIP_CHECK(hipStreamWaitEvent(ax, e->ev_fork, 0));
+        if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], ax));
+        if ((rc = launch_octree(ax, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune)))
+            return rc;
+        if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
+        ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
+        if ((rc = launch_blur(st, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
+        STAGE_MARK(3);
+        ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
     }
-    if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], ax));
-    if ((rc = launch_blur(ax, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
-    if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
-    if (!serial) ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
-    if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune)))
-        return rc;
-    STAGE_MARK(3);
-    if (!serial) ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
     if ((rc = launch_describe(st, nimg, pyr, blur, G, sel, sel_count, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts, capacity,
                               status)))
         return rc;

@@ -104,7 +104,8 @@ void set_error(const char *fmt, ...);
 // Test / measurement hooks of an extractor handle, read from the environment once, when the handle is created
 // (never on a launch path): ORBGPU_FAST_QUEUE_CAP caps the FAST kernel's survivor queue (0: by geometry),
 // ORBGPU_OCT_THREADS = 128 / 256 / 512 forces the batched quadtree's workgroup size (0: by geometry).
-struct LaunchTuning { int fast_queue_cap = 0, oct_threads = 0; };
+// ORBGPU_SCHEDULE = 1 / 2 forces the blur / the quadtree onto the second stream (0: by geometry).
+struct LaunchTuning { int fast_queue_cap = 0, oct_threads = 0, schedule = 0; };
 
 // Where the host-image path of an extractor handle leaves its results (extractor_api.hip).
 struct HostExtraction {

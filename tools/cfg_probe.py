@@ -21,7 +21,7 @@ elif which == "euroc_stereo":
 elif which == "euroc_search":
     r = bench.cfg_euroc_search(torch, dev, B)
 elif which == "4k":
-    r = bench.cfg_4k(torch, dev, B, [B])
+    r = bench.cfg_4k(torch, dev, max(B, 32), [(B, 1), (32, 1), (32, 2), (32, 4)])
 else:
     r = bench.cfg_bruteforce(torch, dev, 100000)
 print(json.dumps(r))
