@@ -23,6 +23,17 @@ namespace orbgpu {
 // kernel reads back, that wait (about a microsecond per barrier for a lone workgroup) buys nothing.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Bits 32 .. 47 of the product of two unsigned 24-bit values, a full-rate instruction (the 32-bit multiply-high is a
+// quarter-rate one).  The vertical pass of the resize needs (b * h) >> 16 with the weight b <= 2^11 and the
+// horizontal sum h < 2^15 kept with its four fraction bits cleared (x & ~15 = h << 4): (b << 12) * (x & ~15) =
+// b * h * 2^16, whose bits 32 .. 47 are (b * h) >> 16.
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int NW>
 __device__ __forceinline__ void store_row_span(uint8_t *row, int x0, int n, const uint32_t (&v)[NW])
 {
@@ -185,18 +196,19 @@ __global__ __launch_bounds__(kRH / 8 * 64) void k_pyr_resize(uint8_t *__restrict
             hA0 = hB0; hA1 = hB1;
         } else {
             const uint8_t *R = L + (yv.sy0 - sy_min) * P * 4;
-            hA0 = (R[xo0] * a00 + R[xr0] * a01) >> 4;
-            hA1 = (R[xo1] * a10 + R[xr1] * a11) >> 4;
+            hA0 = (R[xo0] * a00 + R[xr0] * a01) & ~15;
+            hA1 = (R[xo1] * a10 + R[xr1] * a11) & ~15;
         }
         {
             const uint8_t *R = L + (yv.sy1 - sy_min) * P * 4;
-            hB0 = (R[xo0] * a00 + R[xr0] * a01) >> 4;
-            hB1 = (R[xo1] * a10 + R[xr1] * a11) >> 4;
+            hB0 = (R[xo0] * a00 + R[xr0] * a01) & ~15;
+            hB1 = (R[xo1] * a10 + R[xr1] * a11) & ~15;
         }
-        // (b * h) >> 16 as the high word of (b << 16) * h: the weights are 0 .. 2048 and uniform over the wave
-        const uint32_t B0 = (uint32_t)yv.b0 << 16, B1 = (uint32_t)yv.b1 << 16;
-        const int p0 = (int)(__umulhi(B0, (uint32_t)hA0) + __umulhi(B1, (uint32_t)hB0) + 2u) >> 2;
-        const int p1 = (int)(__umulhi(B0, (uint32_t)hA1) + __umulhi(B1, (uint32_t)hB1) + 2u) >> 2;
+        // (b * h) >> 16 by the 24-bit multiply-high (mulhi_u24): the weights are 0 .. 2048 and uniform over the wave, the
+        // horizontal sums are kept as h << 4
+        const uint32_t B0 = (uint32_t)yv.b0 << 12, B1 = (uint32_t)yv.b1 << 12;
+        const int p0 = (int)(mulhi_u24(B0, (uint32_t)hA0) + mulhi_u24(B1, (uint32_t)hB0) + 2u) >> 2;
+        const int p1 = (int)(mulhi_u24(B0, (uint32_t)hA1) + mulhi_u24(B1, (uint32_t)hB1) + 2u) >> 2;
         // the row and, for rows next to the top / bottom edge, its reflect-101 image in the halo (tabulated)
         const int ym = (yv.pad & 0xFFFF) - 32;
         if (n >= 1) {
@@ -206,6 +218,109 @@ __global__ __launch_bounds__(kRH / 8 * 64) void k_pyr_resize(uint8_t *__restrict
             *reinterpret_cast<uint16_t *>(D + y * gd.pitch + dcol) = v;
             if (ym != y) *reinterpret_cast<uint16_t *>(D + ym * gd.pitch + dcol) = v;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Batches: all levels above 0 of a frame by ONE workgroup, one launch for the whole batch.  A launch per level
+// (k_pyr_resize) makes a batch wait seven times for its slowest workgroup, and the small levels neither fill the
+// chip nor amortise their launch.  Here a workgroup of kWalkWaves waves walks its frame's levels: a wave takes
+// 128 x 8 output tiles of the level (its own LDS window, filled by direct global -> LDS loads and read by nobody
+// else, so tiles need no barrier), and the workgroup meets once per level, when the level it has just written (its
+// stores acknowledged, visible to the waves of its CU) becomes the next one's source.  The arithmetic is that of
+// k_pyr_resize.  The other workgroups of the CU fill the waits.
+// ---------------------------------------------------------------------------
+constexpr int kWalkWaves = 16;
+__global__ __launch_bounds__(kWalkWaves * 64) void k_pyr_walk(uint8_t *__restrict__ pyr, Geom G, const XTab *__restrict__ xtab,
+                                                              const YTab *__restrict__ ytab, int lds_wave_dw)
+{
+    extern __shared__ __align__(16) uint32_t walk_lds[];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    uint8_t *base = pyr + (int64_t)f * G.pyr_frame_bytes;
+    uint32_t *mine = walk_lds + (size_t)wv * lds_wave_dw;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(rs_lvoid *)mine);
+    const uint8_t *L = reinterpret_cast<const uint8_t *>(mine);
+#pragma unroll 1
+    for (int level = 1; level < G.nlevels; level++) {
+        const LevelGeom &gd = G.lv[level];
+        const LevelGeom &gs = G.lv[level - 1];
+        const XTab *xt = xtab + gd.xtab_off;
+        const YTab *yt = ytab + gd.ytab_off;
+        const int tilesX = (gd.w + kRW - 1) / kRW, ntiles = tilesX * ((gd.h + 7) >> 3);
+        // the window's rows are staged 16 bytes per lane: PQ quads per row (the last one may run up to 12 bytes past the
+        // row's last tap: inside the plane's right margin)
+        const int PQ = (gd.rs_pitch_dw + 3) >> 2, P = PQ * 4;
+        const uint32_t magic = 0xFFFFFFFFu / (uint32_t)PQ + 1u;
+        uint8_t *D = base + interior_off(gd);
+#pragma unroll 1
+        for (int t = wv; t < ntiles; t += kWalkWaves) {
+            const int tyi = t / tilesX, dy0 = tyi * 8, tx0 = (t - tyi * tilesX) * kRW;
+            // source window of the tile: columns sx_al .. (last tap + 1), rows sy_min .. sy1 of the tile's last row
+            const int sx_al = xt[tx0].sx & ~3;
+            const int ndw = ((xt[min(tx0 + kRW - 1, gd.w - 1)].sx + 1 - sx_al) >> 2) + 1;
+            const int sy_min = yt[dy0].sy0;
+            const int nrows = yt[min(dy0 + 7, gd.h - 1)].sy1 - sy_min + 1;
+            const uint8_t *S = base + interior_off(gs) + (int64_t)sy_min * gs.pitch + sx_al;  // uniform, dword-aligned
+            const int nq = (ndw + 3) >> 2;
+            const int npieces = (nrows * PQ + 63) >> 6;
+            // the previous tile's LDS reads have returned before the copy engine overwrites the window
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int p = 0; p < npieces; p++) {
+                const uint32_t d = ((uint32_t)p << 6) + (uint32_t)lane;
+                const uint32_t r = __umulhi(d, magic), c = d - r * (uint32_t)PQ;
+                const uint32_t off = min(r, (uint32_t)(nrows - 1)) * (uint32_t)gs.pitch + 16u * min(c, (uint32_t)(nq - 1));
+                const uint32_t dst = lds0 + ((uint32_t)p << 10);
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(off), "s"(S), "s"(dst)
+                             : "memory");
+            }
+            const int dx0 = tx0 + 2 * lane;
+            const XTab t0 = xt[min(dx0, gd.w - 1)], t1 = xt[min(dx0 + 1, gd.w - 1)];
+            YTab ytv[8];  // uniform loads, all in flight at once, fetched while the window is on its way
+#pragma unroll
+            for (int r = 0; r < 8; r++) ytv[r] = yt[min(dy0 + r, gd.h - 1)];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the right tap is the next byte: its weight is 0 where the reference clamps it
+            const int xo0 = t0.sx - sx_al, xo1 = t1.sx - sx_al;
+            int xr0 = xo0 + 1, xr1 = xo1 + 1;  // kept opaque: two byte reads, not one 16-bit read at an odd LDS address
+            asm("" : "+v"(xr0), "+v"(xr1));
+            const int a00 = t0.a0, a01 = t0.a1, a10 = t1.a0, a11 = t1.a1;
+            const uint32_t dcol = (uint32_t)dx0;
+            const int n = gd.w - dx0;  // columns of this lane inside the level: <= 0 none, 1 the first only
+            int hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int y = dy0 + r;
+                if (y >= gd.h) break;
+                const YTab yv = ytv[r];
+                if (r > 0 && (yv.pad & 0x10000)) {
+                    hA0 = hB0; hA1 = hB1;
+                } else {
+                    const uint8_t *R = L + (yv.sy0 - sy_min) * P * 4;
+                    hA0 = (R[xo0] * a00 + R[xr0] * a01) & ~15;
+                    hA1 = (R[xo1] * a10 + R[xr1] * a11) & ~15;
+                }
+                {
+                    const uint8_t *R = L + (yv.sy1 - sy_min) * P * 4;
+                    hB0 = (R[xo0] * a00 + R[xr0] * a01) & ~15;
+                    hB1 = (R[xo1] * a10 + R[xr1] * a11) & ~15;
+                }
+                const uint32_t B0 = (uint32_t)yv.b0 << 12, B1 = (uint32_t)yv.b1 << 12;  // (b * h) >> 16: see mulhi_u24
+                const int p0 = (int)(mulhi_u24(B0, (uint32_t)hA0) + mulhi_u24(B1, (uint32_t)hB0) + 2u) >> 2;
+                const int p1 = (int)(mulhi_u24(B0, (uint32_t)hA1) + mulhi_u24(B1, (uint32_t)hB1) + 2u) >> 2;
+                const int ym = (yv.pad & 0xFFFF) - 32;
+                if (n >= 1) {
+                    const uint16_t v = (uint16_t)(p0 | (p1 << 8));
+                    *reinterpret_cast<uint16_t *>(D + y * gd.pitch + dcol) = v;
+                    if (ym != y) *reinterpret_cast<uint16_t *>(D + ym * gd.pitch + dcol) = v;
+                }
+            }
+        }
+        // the level is complete and visible to this workgroup's waves before any of them reads it as a source
+        __syncthreads();
     }
 }
 
@@ -1766,9 +1881,18 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr
 // ---------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------
+constexpr int kWalkMinFrames = 128;  // from here on a workgroup per frame fills the chip
+
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
                    const Geom &G_, const XTab *xtab, const YTab *ytab, const FuseArgs *fuse)
 {
+    // LDS window of one wave's 128 x 8 tile in k_pyr_walk: the largest over the levels, padded to whole 64-dword pieces
+    int walk_lds_dw = 0;
+    for (int l = 1; l < G_.nlevels; l++) {
+        const int dw = (G_.lv[l].rs_rows8 * ((G_.lv[l].rs_pitch_dw + 3) & ~3) + 255 + 256) & ~255;  // rows of whole quads, whole 1 KiB pieces
+        walk_lds_dw = dw > walk_lds_dw ? dw : walk_lds_dw;
+        if (G_.lv[l].rs_rows8 <= 0) walk_lds_dw = -(1 << 30);
+    }
     // the XCD-pinned frame mapping (nimg >= 8) pays off for the kernels that re-read shared rows
     // (resize, blur, describe); the streaming ones keep the plain mapping (nimg = 0)
     Geom G = G_;
@@ -1781,6 +1905,12 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
         const size_t lds = (size_t)fuse->lds_entries * 24 + 2 * (size_t)fuse->lds_half;
         hipLaunchKernelGGL(k_pyr_fused, dim3(((gl.w + kFW - 1) / kFW) * ((gl.h + kFH - 1) / kFH), nimg), dim3(1024), lds, st, pyr, G, 1,
                            G.nlevels - 1, xtab, ytab, fuse->tab, fuse->lds_entries, fuse->lds_half);
+        ORBGPU_HIP_CHECK(hipGetLastError());
+        return ORBGPU_OK;
+    }
+    // a batch: one workgroup per frame walks the levels (one launch); the per-wave windows must fit the CU's LDS twice
+    if (nimg >= kWalkMinFrames && G.nlevels > 1 && walk_lds_dw > 0 && (size_t)walk_lds_dw * 4 * kWalkWaves <= 64 * 1024) {
+        hipLaunchKernelGGL(k_pyr_walk, dim3(nimg), dim3(kWalkWaves * 64), (size_t)walk_lds_dw * 4 * kWalkWaves, st, pyr, G, xtab, ytab, walk_lds_dw);
         ORBGPU_HIP_CHECK(hipGetLastError());
         return ORBGPU_OK;
     }

@@ -338,6 +338,12 @@ if (g.node_cap > (1 << 20)) {
                 const int rows = Y[ty0 + kRH - 1 < g.h ? ty0 + kRH - 1 : g.h - 1].sy1 - Y[ty0].sy0 + 1;
                 maxrows = rows > maxrows ? rows : maxrows;
             }
+            int maxrows8 = 1;
+            for (int ty0 = 0; ty0 < g.h; ty0 += 8) {
+                const int rows = Y[ty0 + 7 < g.h ? ty0 + 7 : g.h - 1].sy1 - Y[ty0].sy0 + 1;
+                maxrows8 = rows > maxrows8 ? rows : maxrows8;
+            }
+            g.rs_rows8 = maxrows8;
             g.rs_rows = maxrows;
             g.rs_pitch_dw = maxdw | 1;
             g.rs_magic = 0xFFFFFFFFu / (uint32_t)g.rs_pitch_dw + 1u;

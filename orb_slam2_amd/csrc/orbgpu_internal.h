@@ -54,7 +54,7 @@ struct LevelGeom {
     int32_t patch_size;      // (int)(31*scale)
     int32_t rs_rows, rs_pitch_dw;  // resize into this level: staged source rows / dwords per row of the largest tile
     uint32_t rs_magic;       // floor(2^32 / rs_pitch_dw) + 1: dword index -> row of the staged window by one multiply
-    int32_t rs_reserved;
+    int32_t rs_rows8;        // staged source rows of the largest 8-row tile (k_pyr_walk)
     int64_t plane_off;       // byte offset of the level's allocation within a frame's pyramid
     int64_t slot_off;        // u32 offset of the level's cell slots within a frame
     int64_t cand_off;        // u32 offset of the level's candidate arrays within a frame

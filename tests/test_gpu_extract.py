@@ -216,6 +216,35 @@ def test_batch_of_64_dense_frames(oracle):
         assert int((res[i][1] != odesc).any(axis=1).sum()) <= 0.001 * len(odesc)
 
 
+def test_batch_of_160_frames_level_walk(oracle):
+    """From 128 frames per launch on, a workgroup per frame walks the pyramid levels in one launch (k_pyr_walk) instead
+    of one launch per level: every level of several frames (halo rows included) equals the single-frame pyramid, and
+    every frame's extraction equals its single-frame extraction.  Device-resident batch: one launch of 160."""
+    from hiputil import Hip
+    from orb_slam2_amd.api import KEYPOINT_DTYPE
+    n, w, h = 160, 752, 480  # a width that leaves the last 128-column tile partly empty
+    seq = synth.sequence(w, h, n, seed=15, per_frame_density=True)
+    ex = _mk(w, h, 1200, max_batch=n)
+    one = _mk(w, h, 1200)
+    cap = ex.max_keypoints
+    hip = Hip()
+    try:
+        d_img = hip.upload(seq)
+        d_k, d_d, d_c = hip.alloc(n * cap * 28), hip.alloc(n * cap * 32), hip.alloc(n * 4)
+        ex.extract_batch_device(d_img.value, n, w, h, w, w * h, d_k.value, d_d.value, cap, d_c.value)
+        ex.sync()
+        K, D, Cn = hip.download(d_k, (n, cap), KEYPOINT_DTYPE), hip.download(d_d, (n, cap, 32), np.uint8), hip.download(d_c, n, np.int32)
+    finally:
+        hip.free()
+    for i in (0, 77, 159):
+        k1, d1 = one(seq[i])
+        for l in range(8):
+            assert np.array_equal(ex.pyramid_level(l, frame=i, border=19)[:, 19:-19], one.pyramid_level(l, border=19)[:, 19:-19]), (i, l)
+    for i in range(n):
+        k1, d1 = one(seq[i])
+        assert Cn[i] == len(k1) and np.array_equal(K[i, :Cn[i]], k1) and np.array_equal(D[i, :Cn[i]], d1), "frame %d" % i
+
+
 def test_frame_size_changes_on_one_handle(oracle):
     """A handle sized for 640x480 is given smaller frames and the first size again, through the single-frame call and
     the batch call: the tables, buffers and the replayed launch sequence follow the frame size, and every result equals
