@@ -14,6 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from orb_slam2_amd import api, synth  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # hiputil
 from oracle import oracle as O  # noqa: E402  (the checker)
 
 KINDS = ["scene", "noise", "lownoise", "blocks", "checker", "dots", "saturated", "smooth"]
@@ -321,6 +322,76 @@ def compare_frame(m, ex, ex2, img, img2, a, b, w, h, nlevels, rng):
     return None
 
 
+def compare_batch(m, img, img2, a, b, w, h, nfeat, scale, nlevels, ini, mn, gauss, rng):
+    """The batch entry points on device-resident data: orbgpu_extract_batch_device of a few views, then
+    orbgpu_stereo_match_batch_device (left = views, right = the same views in another order),
+    orbgpu_search_for_initialization_batch_device between them, and the brute-force scan on both kernels."""
+    from hiputil import Hip
+    B = int(rng.integers(2, 6))
+    views = [img, img2] + [(np.roll(img, int(rng.integers(-3, 4)), 1).astype(np.int16) + rng.integers(-2, 3, img.shape)).clip(0, 255).astype(np.uint8)
+                           for _ in range(B - 2)]
+    left = np.stack(views)
+    right = np.stack([views[(i + 1) % B] for i in range(B)])
+    exL = api.ORBextractor(nfeat, scale, nlevels, ini, mn, max_width=w, max_height=h, gauss_variant=gauss, max_batch=B)
+    exR = api.ORBextractor(nfeat, scale, nlevels, ini, mn, max_width=w, max_height=h, gauss_variant=gauss, max_batch=B)
+    cap = exL.max_keypoints
+    fx = float(rng.uniform(200, 900))
+    bf = fx * float(rng.uniform(0.05, 0.6))
+    win = int(rng.integers(5, 300))
+    ratio, ori = float(rng.uniform(0.5, 1.0)), bool(rng.integers(2))
+    mi = api.ORBmatcher(ratio, ori)
+    bounds = np.array([0, 0, w, h], np.float32)
+    hip = Hip()
+    try:
+        dimg = [hip.upload(left), hip.upload(right)]
+        kk = [hip.alloc(B * cap * 28) for _ in range(2)]; dd = [hip.alloc(B * cap * 32) for _ in range(2)]; cc = [hip.alloc(B * 4) for _ in range(2)]
+        for e, i in ((exL, 0), (exR, 1)):
+            e.extract_batch_device(dimg[i].value, B, w, h, w, w * h, kk[i].value, dd[i].value, cap, cc[i].value)
+            e.sync()
+        uR, dep, nv = hip.alloc(B * cap * 4), hip.alloc(B * cap * 4), hip.alloc(B * 4)
+        m12, nm = hip.alloc(B * cap * 4), hip.alloc(B * 4)
+        m.stereo_match_batch_device(exL, exR, B, kk[0].value, dd[0].value, cc[0].value, cap, kk[1].value, dd[1].value, cc[1].value, cap,
+                                    bf, bf / fx, uR.value, dep.value, nv.value)
+        m.sync()
+        mi.search_for_initialization_batch_device(B, kk[0].value, dd[0].value, cc[0].value, cap, kk[1].value, dd[1].value, cc[1].value, cap,
+                                                  bounds, m12.value, nm.value, windowSize=win)
+        mi.sync()
+        N = [hip.download(cc[i], B, np.int32) for i in range(2)]
+        K = [hip.download(kk[i], (B, cap), api.KEYPOINT_DTYPE) for i in range(2)]
+        D = [hip.download(dd[i], (B, cap, 32), np.uint8) for i in range(2)]
+        UR, DEP, NV = hip.download(uR, (B, cap), np.float32), hip.download(dep, (B, cap), np.float32), hip.download(nv, B, np.int32)
+        M12, NM = hip.download(m12, (B, cap), np.int32), hip.download(nm, B, np.int32)
+    finally:
+        hip.free()
+    sc = np.asarray(exL.GetScaleFactors(), np.float32); isc = np.asarray(exL.GetInverseScaleFactors(), np.float32)
+    for p in range(B):
+        kL, kR, dL, dR = K[0][p, :N[0][p]], K[1][p, :N[1][p]], D[0][p, :N[0][p]], D[1][p, :N[1][p]]
+        if p == 0 and (len(kL) != len(a[0]) or not np.array_equal(kL["x"], a[0]["x"]) or not np.array_equal(dL, a[1])):
+            return "batch of %d: frame 0 differs from its single-frame extraction" % B
+        pyrL = [exL.pyramid_level(l, frame=p) for l in range(nlevels)]; pyrR = [exR.pyramid_level(l, frame=p) for l in range(nlevels)]
+        rn, ruR, rdep = O.stereo_matches(kL.view(O.KEYPOINT_DTYPE), dL, kR.view(O.KEYPOINT_DTYPE), dR, pyrL, pyrR, sc, isc, bf, bf / fx)
+        if NV[p] != rn or not np.array_equal(UR[p, :len(kL)], ruR) or not np.array_equal(DEP[p, :len(kL)], rdep):
+            return "stereo batch of %d, pair %d, bf %.3f fx %.3f: %d vs %d with a depth" % (B, p, bf, fx, NV[p], rn)
+        prev = np.stack([kL["x"], kL["y"]], 1).astype(np.float32).reshape(-1)
+        rni, rm12, _ = O.search_for_initialization(kL.view(O.KEYPOINT_DTYPE), dL, kR.view(O.KEYPOINT_DTYPE), dR, bounds, prev, win, ratio, ori)
+        if NM[p] != rni or not np.array_equal(M12[p, :len(kL)], rm12):
+            return "SearchForInitialization batch of %d, pair %d, window %d ratio %.3f ori %d: %d vs %d" % (B, p, win, ratio, ori, NM[p], rni)
+    # brute force: frame 0's descriptors against frame 1's (with a few duplicated rows: ties), both kernels
+    Q, T = D[0][0, :N[0][0]], D[1][0, :N[1][0]]
+    if len(Q) and len(T):
+        T = T.copy(); T[rng.integers(0, len(T), 3)] = T[0]
+        ref = O.bruteforce(Q, T)
+        for which in (1, 2):
+            m.set_bruteforce_kernel(which)
+            try:
+                got = m.BruteForce(Q, T)
+            finally:
+                m.set_bruteforce_kernel(0)
+            if not all(np.array_equal(g, r) for g, r in zip(got, ref)):
+                return "brute force %d x %d on kernel %d differs" % (len(Q), len(T), which)
+    return None
+
+
 def main(argv=None, stats_out=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
@@ -391,6 +462,8 @@ def main(argv=None, stats_out=None):
                 err = compare_bow(a, rng)
             if err is None and rng.random() < 0.5:
                 err = compare_frame(m, ex, ex2, img, img2, a, b, w, h, nlevels, rng)
+            if err is None and rng.random() < 0.3 and w * h <= 800 * 800:
+                err = compare_batch(m, img, img2, a, b, w, h, nfeat, scale, nlevels, ini, mn, gauss, rng)
             nmatch += 1
         if err is not None:
             nfail += 1
