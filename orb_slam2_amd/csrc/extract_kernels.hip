@@ -2010,7 +2010,7 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several
     const bool batch = nimg * G.nlevels >= 256;
     int threads = !batch ? 1024 : maxcap <= 512 ? 128 : nimg * G.nlevels >= 2048 ? 256 : 512;
-    if (batch && tune.oct_threads) threads = tune.oct_threads;  // measurement hook
+    if (tune.oct_threads) threads = tune.oct_threads;  // measurement hook
     const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
     size_t dyn = coff_off + (size_t)(threads + 1) * 4;
     if (batch) {
