@@ -823,13 +823,26 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t *__re
 // order: the new list is reverse(children in creation order) ++ (nodes not in
 // S, in their old order).  Points of a node are a contiguous, order-preserving
 // range of packed candidates in one of two candidate buffers; a split is a
-// stable 4-way partition of that range into the other buffer.
+// 4-way partition of that range into the other buffer.
+//
+// The order of the points inside a node does not matter to the tree: boxes and
+// populations decide every step.  It matters once, at the end, where the
+// reference keeps the first of several points that share the best response in
+// a node's vector (:984-996, strict >), and that vector is in the order the
+// cells were visited (:1087-1130: cell row, cell column, then cv::FAST's
+// row-major order inside the cell).  That rank is a function of the point's
+// position alone, so the last step orders ties by (cell row, cell column, y, x)
+// and the partitions are free to be unstable: the roots and every node of more
+// than kBigNode points are split by all waves at once through atomic cursors
+// (a stable split of such a node costs two workgroup scans per 1024 points).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int qn_count(const QNode &n) { return n.count & 0x7FFFFFFF; }
 __device__ __forceinline__ int qn_buf(const QNode &n) { return (int)((uint32_t)n.count >> 31); }
 
 constexpr int kBigNode = 512;  // nodes above this many points are split by the whole workgroup
 constexpr int kQuadNode = 48;  // four nodes of at most this many points each share a wave, sixteen lanes per node
+constexpr int kBigGroup = 32;  // big nodes scattered between two barriers (four LDS cursors each)
+constexpr int kOctUnroll = 4;  // 64-point pieces a wave has in flight
 
 // bits 16 g .. 16 g + 15 of a ballot: the lanes of sixteen-lane group g
 __device__ __forceinline__ uint32_t sub16(uint64_t b, int g)
@@ -846,8 +859,10 @@ struct OctCtx {
     int32_t *cbase;   // node_cap: exclusive prefix of non-empty children per S entry
     int32_t *mark;    // node_cap: 1 where the list node is in S
     int32_t *big;     // node_cap: S entries whose node holds more than kBigNode points
-    int *scan_lds;
-    int *lds4;        // 4 LDS counters
+    int *scan_lds;    // 32 ints (block_scan1)
+    int *bigcur;      // 4 * kBigGroup LDS cursors
+    int par;          // call parity of block_scan1
+    int thr;          // nodes of more points than this are split by all waves (set by oct_count)
     __device__ __forceinline__ uint32_t *buf(int i) const { return i ? buf1 : buf0; }
     __device__ __forceinline__ QNode *nl(int i) const { return i ? nl1 : nl0; }
 };
@@ -857,27 +872,35 @@ __device__ __forceinline__ int quadrant_of(uint32_t p, int midx, int midy)
     return (cand_x(p) < midx ? 0 : 1) | (cand_y(p) < midy ? 0 : 2);
 }
 
-// Count quadrant populations of S[0..nS): one wave per small node, the whole
-// workgroup for each big node.  Returns the number of big nodes (c.big).
-__device__ int oct_count(const OctCtx &c, int cur, int nS)
+// Count quadrant populations of S[0..nS): a wave (or sixteen lanes) per small node, all waves
+// for each big node.  Returns the number of big nodes (c.big); the sums of the big nodes are
+// complete after the caller's next barrier.
+__device__ int oct_count(OctCtx &c, int cur, int nS)
 {
-    const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wid = tid >> 6, nw = nt >> 6;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6;  // nw: a power of two
     const QNode *nl = c.nl(cur);
+    // few nodes (the early rounds): a wave per node would leave most waves idle, so every node of more than a
+    // wave's worth of points is cut into 64-point pieces that are dealt to all waves
+    const int thr = nS < 4 * nw ? 64 : kBigNode;
+    c.thr = thr;
     int nB = 0;
     for (int b = 0; b < nS; b += nt) {
         const int e = b + tid;
-        const int flag = (e < nS) ? (qn_count(nl[c.S[e]]) > kBigNode) : 0;
+        const int flag = (e < nS) ? (qn_count(nl[c.S[e]]) > thr) : 0;
         int total;
-        const int ex = block_scan_excl(flag, &total, c.scan_lds);
-        if (flag) c.big[nB + ex] = e;
+        const int ex = block_scan1(flag, &total, c.scan_lds, c.par);
+        if (flag) {
+            c.big[nB + ex] = e;
+            c.cnt4[4 * e + 0] = 0; c.cnt4[4 * e + 1] = 0; c.cnt4[4 * e + 2] = 0; c.cnt4[4 * e + 3] = 0;  // summed by atomics below
+        }
         nB += total;
     }
     __syncthreads();
-    // small nodes: a wave takes four consecutive S entries.  While none of the four holds more than kQuadNode
-    // points (the late rounds: many nodes of a few points each) sixteen lanes work on each; otherwise the wave
-    // takes them one after the other.
-    for (int e0 = 4 * wid; e0 < nS; e0 += 4 * nw) {
-        const int grp = lane >> 4, sl = lane & 15, eg = e0 + grp;
+    // small nodes: a wave takes four S entries (nw apart, so that a handful of nodes spreads over the waves).  While
+    // none of the four holds more than kQuadNode points (the late rounds: many nodes of a few points each) sixteen
+    // lanes work on each; otherwise the wave takes them one after the other.
+    for (int base = 0; base < nS; base += 4 * nw) {
+        const int grp = lane >> 4, sl = lane & 15, eg = base + grp * nw + wid;
         QNode ng = {};
         int cntg = 0;
         if (eg < nS) {
@@ -901,10 +924,10 @@ __device__ int oct_count(const OctCtx &c, int cur, int nS)
             }
             continue;
         }
-        for (int e = e0; e < min(e0 + 4, nS); e++) {
+        for (int e = base + wid; e < min(base + 4 * nw, nS); e += nw) {
             const QNode n = nl[c.S[e]];
             const int cnt = qn_count(n);
-            if (cnt > kBigNode) continue;
+            if (cnt > thr) continue;
             const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
             const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -921,31 +944,65 @@ __device__ int oct_count(const OctCtx &c, int cur, int nS)
             }
         }
     }
-    for (int bi = 0; bi < nB; bi++) {
-        const int e = c.big[bi];
-        const QNode n = nl[c.S[e]];
-        const int cnt = qn_count(n);
-        const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
-        const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-        if (tid < 4) c.lds4[tid] = 0;
-        __syncthreads();
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        for (int b = wid * 64; b < cnt; b += nt) {
-            const int i = b + lane;
-            const int q = (i < cnt) ? quadrant_of(pts[i], midx, midy) : -1;
-            c0 += __popcll(__ballot(q == 0));
-            c1 += __popcll(__ballot(q == 1));
-            c2 += __popcll(__ballot(q == 2));
-            c3 += __popcll(__ballot(q == 3));
+    // big nodes: their 64-point pieces are numbered through and dealt round the waves.  Lane l fetches what the
+    // pieces of the l-th node of a group need and the prefix of the piece counts; a piece finds its node by one ballot
+    // over the prefixes and gets the node's data by lane reads: one chain of dependent loads per 64 nodes, not per
+    // node.  kOctUnroll pieces are fetched before the first is counted (the points of a large level are in global
+    // memory: a wave that fetched them one by one would spend its time waiting).
+    for (int g0 = 0; g0 < nB; g0 += 64) {
+        const int ng = min(64, nB - g0);
+        int me = 0, mstart = 0, mcb = 0, mmid = 0, mnc = 0;
+        if (lane < ng) {
+            me = c.big[g0 + lane];
+            const QNode n = nl[c.S[me]];
+            mstart = n.start;
+            mcb = n.count;
+            mmid = (n.x0 + ((n.x1 - n.x0 + 1) >> 1)) | ((n.y0 + ((n.y1 - n.y0 + 1) >> 1)) << 16);
+            mnc = (qn_count(n) + 63) >> 6;
         }
-        if (lane == 0) {
-            atomicAdd(&c.lds4[0], c0); atomicAdd(&c.lds4[1], c1); atomicAdd(&c.lds4[2], c2); atomicAdd(&c.lds4[3], c3);
+        const int mincl = wave_scan_incl(mnc), mexcl = mincl - mnc;
+        const int npieces = __builtin_amdgcn_readlane(mincl, 63);
+        // a wave's consecutive pieces mostly belong to one node: it adds up in registers and sends the sums when
+        // the node changes (thousands of atomic adds to one address would queue up in L2)
+        int cur_e = -1, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int P0 = wid; P0 < npieces; P0 += kOctUnroll * nw) {
+            uint32_t pv[kOctUnroll];
+            int ev[kOctUnroll], midv[kOctUnroll];
+            bool onv[kOctUnroll];
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) {
+                const int P = P0 + u * nw;
+                const int bj = P < npieces ? (int)__popcll(__ballot(mincl <= P)) : 0;  // the lanes behind the group hold npieces
+                const int cb = __builtin_amdgcn_readlane(mcb, bj);
+                const int i = ((P - __builtin_amdgcn_readlane(mexcl, bj)) << 6) + lane;
+                ev[u] = P < npieces ? __builtin_amdgcn_readlane(me, bj) : -1;
+                midv[u] = __builtin_amdgcn_readlane(mmid, bj);
+                onv[u] = P < npieces && i < (cb & 0x7FFFFFFF);
+                pv[u] = onv[u] ? (c.buf((int)((uint32_t)cb >> 31)) + __builtin_amdgcn_readlane(mstart, bj))[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) {
+                if (ev[u] != cur_e) {
+                    if (cur_e >= 0 && lane < 4) {
+                        const int v = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
+                        if (v) atomicAdd(&c.cnt4[4 * cur_e + lane], v);
+                    }
+                    cur_e = ev[u];
+                    c0 = c1 = c2 = c3 = 0;
+                }
+                const int q = onv[u] ? quadrant_of(pv[u], midv[u] & 0xFFFF, midv[u] >> 16) : -1;
+                c0 += __popcll(__ballot(q == 0));
+                c1 += __popcll(__ballot(q == 1));
+                c2 += __popcll(__ballot(q == 2));
+                c3 += __popcll(__ballot(q == 3));
+            }
         }
-        __syncthreads();
-        if (tid < 4) c.cnt4[4 * e + tid] = c.lds4[tid];
-        __syncthreads();
+        if (cur_e >= 0 && lane < 4) {
+            const int v = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
+            if (v) atomicAdd(&c.cnt4[4 * cur_e + lane], v);
+        }
     }
-    return nB;
+    return nB;  // the caller's barrier completes the sums
 }
 
 // Child q (0..3) of node n created by S entry e (ExtractorNode::DivideNode, :606-641).
@@ -968,11 +1025,12 @@ __device__ __forceinline__ void emit_child(const OctCtx &c, int cur, const QNode
 
 // Apply the split of S[0..nS) using cnt4 (nB of them listed in c.big): returns
 // the new list size, the number of children created and the number of children
-// holding more than one point.
-__device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, int *out_size, int *out_children, int *out_expand)
+// holding more than one point.  prefix_of_sorted: S is a prefix of the sorted
+// candidates of a final pass; otherwise it is every node of more than one point.
+__device__ void oct_apply(OctCtx &c, int cur, int size, int nS, int nB, bool prefix_of_sorted, int *out_size, int *out_children, int *out_expand)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int lane = lane_id(), wid = tid >> 6, nw = nt >> 6;
+    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6;
     const QNode *nl = c.nl(cur);
     // children prefix + expandable count
     int carry = 0, nexp = 0;
@@ -988,30 +1046,32 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, in
             }
         }
         int total;
-        const int ex = block_scan_excl(ne | (nx << 16), &total, c.scan_lds);
+        const int ex = block_scan1(ne | (nx << 16), &total, c.scan_lds, c.par);
         if (e < nS) c.cbase[e] = carry + (ex & 0xFFFF);
         carry += total & 0xFFFF;
         nexp += total >> 16;
     }
     const int nchild = carry;
     // survivors: list nodes not in S keep their relative order behind the children
-    for (int i = tid; i < size; i += nt) c.mark[i] = 0;
-    __syncthreads();
-    for (int e = tid; e < nS; e += nt) c.mark[c.S[e]] = 1;
-    __syncthreads();
+    if (prefix_of_sorted) {
+        for (int i = tid; i < size; i += nt) c.mark[i] = 0;
+        __syncthreads();
+        for (int e = tid; e < nS; e += nt) c.mark[c.S[e]] = 1;
+        __syncthreads();
+    }
     carry = 0;
-    for (int b = 0; b < size; b += nt) {
+    for (int b = 0; b < size; b += nt) {  // size >= 1: the barrier of this scan also publishes cbase
         const int i = b + tid;
-        const int keep = (i < size) ? (c.mark[i] == 0) : 0;
+        const int keep = (i < size) ? (prefix_of_sorted ? c.mark[i] == 0 : qn_count(nl[i]) <= 1) : 0;
         int total;
-        const int ex = block_scan_excl(keep, &total, c.scan_lds);
+        const int ex = block_scan1(keep, &total, c.scan_lds, c.par);
         if (keep) c.nl(cur ^ 1)[nchild + carry + ex] = nl[i];
         carry += total;
     }
     // scatter the points and emit the child nodes.  Small nodes: four S entries per wave, sixteen lanes each
     // while all four are small, else one after the other (as in oct_count)
-    for (int e0 = 4 * wid; e0 < nS; e0 += 4 * nw) {
-        const int grp = lane >> 4, sl = lane & 15, eg = e0 + grp;
+    for (int base = 0; base < nS; base += 4 * nw) {
+        const int grp = lane >> 4, sl = lane & 15, eg = base + grp * nw + wid;
         QNode ng = {};
         int cntg = 0;
         if (eg < nS) {
@@ -1047,10 +1107,10 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, in
             if (sl < 4 && eg < nS) emit_child(c, cur, ng, eg, sl, midx, midy, k0, k1, k2, k3, s0, nchild, db);
             continue;
         }
-        for (int e = e0; e < min(e0 + 4, nS); e++) {
+        for (int e = base + wid; e < min(base + 4 * nw, nS); e += nw) {
             const QNode n = nl[c.S[e]];
             const int cnt = qn_count(n), sb = qn_buf(n), db = sb ^ 1;
-            if (cnt > kBigNode) continue;
+            if (cnt > c.thr) continue;
             const uint32_t *pts = c.buf(sb) + n.start;
             uint32_t *dst = c.buf(db);
             const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
@@ -1076,36 +1136,83 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, in
             if (lane < 4) emit_child(c, cur, n, e, lane, midx, midy, k0, k1, k2, k3, s0, nchild, db);
         }
     }
-    // big nodes: the whole workgroup, stable ranks from two packed block scans per 1024 points
-    for (int bi = 0; bi < nB; bi++) {
-        const int e = c.big[bi];
-        if (e >= nS) continue;  // listed by oct_count but outside the prefix being split
-        const QNode n = nl[c.S[e]];
-        const int cnt = qn_count(n), sb = qn_buf(n), db = sb ^ 1;
-        const uint32_t *pts = c.buf(sb) + n.start;
-        uint32_t *dst = c.buf(db);
-        const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-        const int k0 = c.cnt4[4 * e + 0], k1 = c.cnt4[4 * e + 1], k2 = c.cnt4[4 * e + 2], k3 = c.cnt4[4 * e + 3];
-        const int s0 = n.start, s1 = s0 + k0, s2 = s1 + k1, s3 = s2 + k2;
-        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        for (int b = 0; b < cnt; b += nt) {
-            const int i = b + tid;
-            int q = -1;
-            uint32_t p = 0;
-            if (i < cnt) {
-                p = pts[i];
-                q = quadrant_of(p, midx, midy);
+    // big nodes: their 64-point pieces go round the waves (as in oct_count); a piece claims its place in each
+    // child's range with one atomic add per non-empty quadrant
+    for (int g0 = 0; g0 < nB; g0 += kBigGroup) {
+        const int ng = min(kBigGroup, nB - g0);
+        for (int i = tid; i < 4 * ng; i += nt) c.bigcur[i] = 0;
+        int me = 0x7FFFFFFF, mstart = 0, mcb = 0, mmid = 0, mk0 = 0, mk1 = 0, mk2 = 0, mnc = 0, mx = 0, my = 0;
+        if (lane < ng) {
+            me = c.big[g0 + lane];
+            if (me < nS) {  // else: listed by oct_count but outside the prefix being split (no pieces)
+                const QNode n = nl[c.S[me]];
+                mstart = n.start;
+                mcb = n.count;
+                mx = (uint16_t)n.x0 | ((int)n.x1 << 16);
+                my = (uint16_t)n.y0 | ((int)n.y1 << 16);
+                mmid = (n.x0 + ((n.x1 - n.x0 + 1) >> 1)) | ((n.y0 + ((n.y1 - n.y0 + 1) >> 1)) << 16);
+                mk0 = c.cnt4[4 * me + 0]; mk1 = c.cnt4[4 * me + 1]; mk2 = c.cnt4[4 * me + 2];
+                mnc = (qn_count(n) + 63) >> 6;
             }
-            int t01, t23;
-            const int e01 = block_scan_excl((q == 0) | ((q == 1) << 16), &t01, c.scan_lds);
-            const int e23 = block_scan_excl((q == 2) | ((q == 3) << 16), &t23, c.scan_lds);
-            if (q == 0) dst[s0 + r0 + (e01 & 0xFFFF)] = p;
-            else if (q == 1) dst[s1 + r1 + (e01 >> 16)] = p;
-            else if (q == 2) dst[s2 + r2 + (e23 & 0xFFFF)] = p;
-            else if (q == 3) dst[s3 + r3 + (e23 >> 16)] = p;
-            r0 += t01 & 0xFFFF; r1 += t01 >> 16; r2 += t23 & 0xFFFF; r3 += t23 >> 16;
         }
-        if (tid < 4) emit_child(c, cur, n, e, tid, midx, midy, k0, k1, k2, k3, s0, nchild, db);
+        const int mincl = wave_scan_incl(mnc), mexcl = mincl - mnc;
+        const int npieces = __builtin_amdgcn_readlane(mincl, 63);
+        // the child nodes: thread t makes child t & 3 of the group's node t >> 2 (every wave holds all of them)
+        for (int t0 = 0; t0 < 4 * ng; t0 += nt) {
+            const int t = t0 + tid, nd = (t >> 2) & 63;
+            const int e = __shfl(me, nd), cb = __shfl(mcb, nd), xs = __shfl(mx, nd), ys = __shfl(my, nd), mid = __shfl(mmid, nd);
+            const int k0 = __shfl(mk0, nd), k1 = __shfl(mk1, nd), k2 = __shfl(mk2, nd), s0 = __shfl(mstart, nd);
+            if (t < 4 * ng && e < nS) {
+                QNode n;
+                n.x0 = (int16_t)(xs & 0xFFFF); n.x1 = (int16_t)(xs >> 16); n.y0 = (int16_t)(ys & 0xFFFF); n.y1 = (int16_t)(ys >> 16);
+                n.start = s0; n.count = cb;
+                emit_child(c, cur, n, e, t & 3, mid & 0xFFFF, mid >> 16, k0, k1, k2, (cb & 0x7FFFFFFF) - k0 - k1 - k2, s0, nchild,
+                           (int)((uint32_t)cb >> 31) ^ 1);
+            }
+        }
+        __syncthreads();
+        const uint64_t lt = (1ull << lane) - 1ull;
+        for (int P0 = wid; P0 < npieces; P0 += kOctUnroll * nw) {
+            uint32_t pv[kOctUnroll];
+            int bjv[kOctUnroll], qv[kOctUnroll], basev[kOctUnroll];
+            uint64_t mv[kOctUnroll];
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) {
+                const int P = P0 + u * nw;
+                const int bj = P < npieces ? (int)__popcll(__ballot(mincl <= P)) : 0;
+                const int cb = __builtin_amdgcn_readlane(mcb, bj);
+                const int i = ((P - __builtin_amdgcn_readlane(mexcl, bj)) << 6) + lane;
+                bjv[u] = bj;
+                qv[u] = (P < npieces && i < (cb & 0x7FFFFFFF)) ? 0 : -1;
+                pv[u] = qv[u] == 0 ? (c.buf((int)((uint32_t)cb >> 31)) + __builtin_amdgcn_readlane(mstart, bj))[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) {
+                const int mid = __builtin_amdgcn_readlane(mmid, bjv[u]);
+                const int q = qv[u] == 0 ? quadrant_of(pv[u], mid & 0xFFFF, mid >> 16) : -1;
+                qv[u] = q;
+                const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+                mv[u] = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;  // the lanes of this lane's quadrant
+                int base = 0;
+                if (lane < 4) {
+                    const int v = __popcll(lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3);
+                    if (v) base = atomicAdd(&c.bigcur[4 * bjv[u] + lane], v);
+                }
+                basev[u] = base;
+            }
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) {
+                const int bj = bjv[u], q = qv[u];
+                const int s0 = __builtin_amdgcn_readlane(mstart, bj), s1 = s0 + __builtin_amdgcn_readlane(mk0, bj),
+                          s2 = s1 + __builtin_amdgcn_readlane(mk1, bj), s3 = s2 + __builtin_amdgcn_readlane(mk2, bj);
+                const int o0 = __builtin_amdgcn_readlane(basev[u], 0), o1 = __builtin_amdgcn_readlane(basev[u], 1),
+                          o2 = __builtin_amdgcn_readlane(basev[u], 2), o3 = __builtin_amdgcn_readlane(basev[u], 3);
+                const int at = q == 0 ? s0 + o0 : q == 1 ? s1 + o1 : q == 2 ? s2 + o2 : s3 + o3;
+                uint32_t *dst = c.buf((int)((uint32_t)__builtin_amdgcn_readlane(mcb, bj) >> 31) ^ 1);
+                if (q >= 0) dst[at + __popcll(mv[u] & lt)] = pv[u];
+            }
+        }
+        if (g0 + kBigGroup < nB) __syncthreads();  // the next group clears the cursors
     }
     __syncthreads();
     *out_size = nchild + (size - nS);
@@ -1113,7 +1220,7 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nS, int nB, in
     *out_expand = nexp;
 }
 
-template <bool kLdsNodes>
+template <bool kLdsNodes, bool kLdsPts>
 __device__ __forceinline__ void octree_level(const int level, const int f, const Geom &G, const uint32_t *__restrict__ slots,
                                              const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes,
                                              int32_t *scratch, uint32_t *__restrict__ sel,
@@ -1129,13 +1236,25 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
     extern __shared__ __align__(16) unsigned char dyn_lds[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(dyn_lds);
     int *coff = reinterpret_cast<int *>(dyn_lds + dyn_coff_off);  // blockDim.x + 1 cell offsets of the gather
-    __shared__ int scan_lds[33];
+    __shared__ int scan_lds[32];
     __shared__ int root_cnt[kMaxRoots], root_start[kMaxRoots];
-    __shared__ int sh_a, lds4[4];
+    __shared__ int sh_a;
+    static_assert(4 * kBigGroup <= kMaxRoots, "the cursors of the big nodes reuse root_cnt");
 
     const int tid = threadIdx.x, nt = blockDim.x;
     const LevelGeom &g = G.lv[level];
     const int N = g.quota;
+#ifdef ORBGPU_OCT_TRACE
+    // phase times of level 0 of frame 0 (100 MHz clock), printed at the end: a measurement build only
+    unsigned long long tr_t[96];
+    int tr_id[96], ntr = 0;
+    const bool trace_on = level == ORBGPU_OCT_TRACE && f == 0 && tid == 0;
+    const unsigned long long tr_begin = wall_clock64();
+#define OCT_T(id_) do { if (trace_on && ntr < 96) { tr_id[ntr] = id_; tr_t[ntr++] = wall_clock64(); } } while (0)
+#else
+#define OCT_T(id_) do { } while (0)
+#endif
+    OCT_T(0);
     OctCtx c;
     c.buf0 = cand + (int64_t)f * G.cand_frame_u32 + g.cand_off;
     c.buf1 = c.buf0 + g.cand_cap;
@@ -1163,7 +1282,8 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
         c.big = scr + 7 * g.node_cap;
     }
     c.scan_lds = scan_lds;
-    c.lds4 = lds4;
+    c.bigcur = root_cnt;  // free once the roots exist
+    c.par = 0;
     int32_t *out_count = sel_count + f * G.nlevels + level;
     uint32_t *out_sel = sel + (int64_t)f * G.total_kp_cap + g.kp_off;
 
@@ -1172,24 +1292,19 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
     const int32_t *cc = cell_counts + (int64_t)f * G.total_cells + g.cell_off;
     const uint32_t *sl = slots + (int64_t)f * G.slot_frame_u32 + g.slot_off;
     uint32_t *const gathered = c.buf0;  // the gathered candidates are also kept in global memory (orbgpu_debug_level_candidates)
-    if (pts_cap > 0) {
+    if constexpr (kLdsPts) {
         // a level whose candidates fit keeps both candidate buffers in LDS: every subdivision round reads and
-        // re-partitions the points, and in global memory each of those steps is a dependent round trip
-        int mine = 0;
-        for (int ci = tid; ci < nCells; ci += nt) mine += cc[ci];
-        int total;
-        (void)block_scan_excl(mine, &total, scan_lds);
-        if (total <= pts_cap) {
-            c.buf0 = reinterpret_cast<uint32_t *>(dyn_lds + dyn_pts_off);
-            c.buf1 = c.buf0 + pts_cap;
-        }
+        // re-partitions the points, and in global memory each of those steps is a dependent round trip.  (Its own
+        // instance, as for the node lists: the point accesses compile to LDS instructions.)
+        c.buf0 = reinterpret_cast<uint32_t *>(dyn_lds + dyn_pts_off);
+        c.buf1 = c.buf0 + pts_cap;
     }
     int M = 0;
     for (int b = 0; b < nCells; b += nt) {
         const int ci = b + tid;
         const int cnt = ci < nCells ? cc[ci] : 0;
         int total;
-        const int ex = block_scan_excl(cnt, &total, scan_lds);
+        const int ex = block_scan1(cnt, &total, scan_lds, c.par);
         coff[tid] = ex;
         if (tid == 0) coff[nt] = total;
         __syncthreads();
@@ -1202,11 +1317,12 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
             }
             const uint32_t v = sl[(int64_t)(b + lo) * g.cell_cap + (j - coff[lo])];
             c.buf0[M + j] = v;
-            if (c.buf0 != gathered) gathered[M + j] = v;
+            if constexpr (kLdsPts) gathered[M + j] = v;
         }
         __syncthreads();
         M += total;
     }
+    OCT_T(1);
     if (tid == 0) cand_count[f * G.nlevels + level] = M;
     if (M == 0) {
         if (tid == 0) *out_count = 0;
@@ -1219,23 +1335,58 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
     const float hX = g.hX;
     int rb = 0;  // buffer holding the root ranges
     if (nIni > 1) {
-        int outpos = 0;
-        for (int r = 0; r < nIni; r++) {
-            const int start = outpos;
-            for (int b = 0; b < M; b += nt) {
-                const int i = b + tid;
-                uint32_t p = 0;
-                int flag = 0;
-                if (i < M) {
-                    p = c.buf0[i];
-                    flag = ((int)((float)cand_x(p) / hX) == r);
+        // a point's root is (int)(x / hX) (:707-711); the ranges of the roots are filled in any order
+        const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+        int *root_cur = coff;  // the gather is done with it; nt + 1 >= kMaxRoots entries
+        for (int r = tid; r < nIni; r += nt) { root_cnt[r] = 0; root_cur[r] = 0; }
+        __syncthreads();
+        for (int b = wid * 64; b < M; b += kOctUnroll * nt) {
+            uint32_t pv[kOctUnroll];
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) pv[u] = b + u * nt + lane < M ? c.buf0[b + u * nt + lane] : 0u;
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) {
+                int r = b + u * nt + lane < M ? (int)((float)cand_x(pv[u]) / hX) : -1;
+                if (r >= nIni) r = -1;
+                uint64_t todo = __ballot(r >= 0);
+                while (todo) {  // one turn per distinct root among the 64 points (neighbours in x: one or two)
+                    const int leader = __ffsll((unsigned long long)todo) - 1;
+                    const int r0 = __builtin_amdgcn_readlane(r, leader);
+                    const uint64_t m = __ballot(r == r0);
+                    if (lane == leader) atomicAdd(&root_cnt[r0], __popcll(m));
+                    todo &= ~m;
                 }
-                int total;
-                const int ex = block_scan_excl(flag, &total, scan_lds);
-                if (flag) c.buf1[outpos + ex] = p;
-                outpos += total;
             }
-            if (tid == 0) { root_cnt[r] = outpos - start; root_start[r] = start; }
+        }
+        __syncthreads();
+        if (wid == 0) {  // kMaxRoots = 128: two roots per lane
+            const int a = 2 * lane < nIni ? root_cnt[2 * lane] : 0, b2 = 2 * lane + 1 < nIni ? root_cnt[2 * lane + 1] : 0;
+            const int ex = wave_scan_incl(a + b2) - (a + b2);
+            if (2 * lane < nIni) root_start[2 * lane] = ex;
+            if (2 * lane + 1 < nIni) root_start[2 * lane + 1] = ex + a;
+        }
+        __syncthreads();
+        const uint64_t lt = (1ull << lane) - 1ull;
+        for (int b = wid * 64; b < M; b += kOctUnroll * nt) {
+            uint32_t pv[kOctUnroll];
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) pv[u] = b + u * nt + lane < M ? c.buf0[b + u * nt + lane] : 0u;
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) {
+                int r = b + u * nt + lane < M ? (int)((float)cand_x(pv[u]) / hX) : -1;
+                if (r >= nIni) r = -1;
+                uint64_t todo = __ballot(r >= 0);
+                while (todo) {
+                    const int leader = __ffsll((unsigned long long)todo) - 1;
+                    const int r0 = __builtin_amdgcn_readlane(r, leader);
+                    const uint64_t m = __ballot(r == r0);
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(&root_cur[r0], __popcll(m));
+                    base = __builtin_amdgcn_readlane(base, leader);
+                    if (r == r0) c.buf1[root_start[r0] + base + __popcll(m & lt)] = pv[u];
+                    todo &= ~m;
+                }
+            }
         }
         rb = 1;
     } else if (tid == 0) {
@@ -1259,6 +1410,7 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
         }
     }
     __syncthreads();
+    OCT_T(2);
 
     // ---- subdivision rounds (:778-970) -----------------------------------------
     int cur = 0;
@@ -1271,17 +1423,20 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
             const int i = b + tid;
             const int flag = (i < size) ? (qn_count(c.nl(cur)[i]) > 1) : 0;
             int total;
-            const int ex = block_scan_excl(flag, &total, scan_lds);
+            const int ex = block_scan1(flag, &total, scan_lds, c.par);
             if (flag) c.S[nS + ex] = i;
             nS += total;
         }
         __syncthreads();
         if (nS == 0) break;  // nothing can be divided: size == prevSize
+        OCT_T(10);
         const int nB = oct_count(c, cur, nS);
         __syncthreads();
+        OCT_T(11);
         int nchild, nexp;
-        oct_apply(c, cur, size, nS, nB, &size, &nchild, &nexp);
+        oct_apply(c, cur, size, nS, nB, false, &size, &nchild, &nexp);
         cur ^= 1;
+        OCT_T(12);
         if (size >= N || size == prevSize) break;
         if (size + nexp * 3 > N) {
             // ---- final partial passes (:893-968): largest nodes first --------
@@ -1299,34 +1454,52 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
                         flag = cnt > 1;
                     }
                     int total;
-                    const int ex = block_scan_excl(flag, &total, scan_lds);
+                    const int ex = block_scan1(flag, &total, scan_lds, c.par);
                     if (flag) keys[nC + ex] = ((unsigned long long)cnt << 32) | (unsigned)(lastChildren - 1 - i);
                     nC += total;
                 }
                 if (nC == 0) { finish = true; break; }
-                int np2 = 1;
-                while (np2 < nC) np2 <<= 1;
-                for (int i = nC + tid; i < np2; i += nt) keys[i] = 0ull;
-                __syncthreads();
-                for (int k = 2; k <= np2; k <<= 1) {
-                    for (int j = k >> 1; j > 0; j >>= 1) {
-                        for (int i = tid; i < np2; i += nt) {
-                            const int ixj = i ^ j;
-                            if (ixj > i) {
-                                const unsigned long long a = keys[i], bb = keys[ixj];
-                                const bool desc = ((i & k) == 0);
-                                if (desc ? (a < bb) : (a > bb)) { keys[i] = bb; keys[ixj] = a; }
-                            }
-                        }
-                        __syncthreads();
+                OCT_T(20);
+                if ((long long)nC * nC <= (long long)nt * 2048) {
+                    // the keys are distinct: a key's place is the number of larger keys (every lane reads the same
+                    // key at a time, which LDS broadcasts); one barrier instead of the sorting network's dozens
+                    __syncthreads();
+                    for (int i = tid; i < nC; i += nt) {
+                        const unsigned long long k = keys[i];
+                        int rank = 0;
+#pragma unroll 8
+                        for (int j = 0; j < nC; j++) rank += keys[j] > k ? 1 : 0;
+                        c.S[rank] = lastChildren - 1 - (int)(k & 0xFFFFFFFFull);
                     }
+                } else {
+                    int np2 = 1;
+                    while (np2 < nC) np2 <<= 1;
+                    for (int i = nC + tid; i < np2; i += nt) keys[i] = 0ull;
+                    __syncthreads();
+                    for (int k = 2; k <= np2; k <<= 1) {
+                        for (int j = k >> 1; j > 0; j >>= 1) {
+                            for (int i = tid; i < np2; i += nt) {
+                                const int ixj = i ^ j;
+                                if (ixj > i) {
+                                    const unsigned long long a = keys[i], bb = keys[ixj];
+                                    const bool desc = ((i & k) == 0);
+                                    if (desc ? (a < bb) : (a > bb)) { keys[i] = bb; keys[ixj] = a; }
+                                }
+                            }
+                            __syncthreads();
+                        }
+                    }
+                    for (int i = tid; i < nC; i += nt) c.S[i] = lastChildren - 1 - (int)(keys[i] & 0xFFFFFFFFull);
                 }
-                for (int i = tid; i < nC; i += nt) c.S[i] = lastChildren - 1 - (int)(keys[i] & 0xFFFFFFFFull);
                 __syncthreads();
+                OCT_T(21);
                 const int nB2 = oct_count(c, cur, nC);
                 __syncthreads();
+                OCT_T(22);
                 // first j with size + sum_{i<=j}(children_i - 1) >= N
+                // (a split never shrinks the list, so the running size crosses N at one entry only)
                 int acc = size, jstar = -1;
+                if (tid == 0) sh_a = -1;  // ordered before the first write below by the barrier of the scan
                 for (int b = 0; b < nC && jstar < 0; b += nt) {
                     const int e = b + tid;
                     int gain = 0;
@@ -1336,18 +1509,17 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
                         for (int q = 0; q < 4; q++) gain += c.cnt4[4 * e + q] > 0;
                     }
                     int total;
-                    const int ex = block_scan_excl(gain, &total, scan_lds);
-                    if (tid == 0) sh_a = 0x7FFFFFFF;
+                    const int ex = block_scan1(gain, &total, scan_lds, c.par);
+                    if (e < nC && acc + ex < N && acc + ex + gain >= N) sh_a = e;
                     __syncthreads();
-                    if (e < nC && acc + ex + gain >= N) atomicMin(&sh_a, e);
-                    __syncthreads();
-                    if (sh_a != 0x7FFFFFFF) jstar = sh_a;
+                    jstar = sh_a;
                     acc += total;
-                    __syncthreads();
                 }
                 const int nS2 = jstar >= 0 ? jstar + 1 : nC;
-                oct_apply(c, cur, size, nS2, nB2, &size, &nchild, &nexp);
+                OCT_T(23);
+                oct_apply(c, cur, size, nS2, nB2, true, &size, &nchild, &nexp);
                 cur ^= 1;
+                OCT_T(24);
                 if (size >= N || size == prev2) { finish = true; break; }
                 lastChildren = nchild;
             }
@@ -1359,22 +1531,43 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
         if (tid == 0) atomicOr(status, 1);
         size = g.kp_cap;
     }
-    // eight lanes per node
+    // eight lanes per node.  Highest response; among equals the first in the reference's visiting order: cell row,
+    // cell column ((y - 3) / hCell and (x - 3) / wCell: a cell's keypoints start 3 px inside it, :1090-1124), y, x
+    const uint32_t mx = ((1u << 20) + (uint32_t)g.wCell - 1u) / (uint32_t)g.wCell,  // exact quotients below 4096 for
+                   my = ((1u << 20) + (uint32_t)g.hCell - 1u) / (uint32_t)g.hCell;  // divisors up to 256
+    constexpr unsigned long long kRankMask = (1ull << 38) - 1ull;
     for (int e = (tid >> 3); e < size; e += (nt >> 3)) {
         const QNode n = c.nl(cur)[e];
         const int cnt = qn_count(n);
         const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
-        uint32_t best = 0;
+        unsigned long long best = 0;
         for (int i = tid & 7; i < cnt; i += 8) {
-            // highest response, earliest position on ties
-            const uint32_t key = ((uint32_t)cand_s(pts[i]) << 24) | (0xFFFFFFu - (uint32_t)i);
-            best = max(best, key);
+            const uint32_t p = pts[i], x = (uint32_t)cand_x(p), y = (uint32_t)cand_y(p);
+            const uint32_t cx = ((x - 3u) * mx) >> 20, cy = ((y - 3u) * my) >> 20;
+            const unsigned long long rank = ((unsigned long long)cy << 31) | ((unsigned long long)cx << 24) | (y << 12) | x;
+            const unsigned long long key = ((unsigned long long)cand_s(p) << 38) | (kRankMask - rank);
+            best = key > best ? key : best;
         }
 #pragma unroll
-        for (int o = 4; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o));
-        if ((tid & 7) == 0) out_sel[e] = pts[0xFFFFFFu - (best & 0xFFFFFFu)];
+        for (int o = 4; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o);
+            best = other > best ? other : best;
+        }
+        if ((tid & 7) == 0) {
+            const unsigned long long rank = kRankMask - (best & kRankMask);
+            out_sel[e] = pack_cand((int)(rank & 0xFFFu), (int)((rank >> 12) & 0xFFFu), (int)(best >> 38));
+        }
     }
     if (tid == 0) *out_count = size;
+#ifdef ORBGPU_OCT_TRACE
+    OCT_T(30);
+    if (f == 0 && tid == 0) printf("level %d: %6.2f us, M %d size %d N %d\n", level, (double)(wall_clock64() - tr_begin) * 0.01, M, size, N);
+    if (trace_on) {
+        printf("octree trace: M %d size %d N %d\n", M, size, N);
+        for (int i = 1; i < ntr; i++) printf("  phase %2d  +%5.2f us\n", tr_id[i], (double)(tr_t[i] - tr_t[i - 1]) * 0.01);
+    }
+#endif
+#undef OCT_T
 }
 
 #define OCTREE_ARGS                                                                                                          \
@@ -1384,12 +1577,26 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
 // one frame: a few 1024-thread workgroups, each with most of a CU's LDS (candidate buffers included)
 __global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
 {
-    if (lds_nodes)
-        octree_level<true>(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
-                           dyn_coff_off, pts_cap, dyn_pts_off);
+    const int level = blockIdx.x, f = blockIdx.y;
+    bool lds_pts = false;
+    if (pts_cap > 0 && lds_nodes) {  // do this level's candidates fit the LDS left for them?
+        __shared__ int fit_scan[32];
+        const LevelGeom &g = G.lv[level];
+        const int32_t *cc = cell_counts + (int64_t)f * G.total_cells + g.cell_off;
+        int mine = 0, total, par = 0;
+        for (int ci = threadIdx.x; ci < g.nCols * g.nRows; ci += blockDim.x) mine += cc[ci];
+        (void)block_scan1(mine, &total, fit_scan, par);
+        lds_pts = total <= pts_cap;
+    }
+    if (lds_pts)
+        octree_level<true, true>(level, f, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                                 dyn_coff_off, pts_cap, dyn_pts_off);
+    else if (lds_nodes)
+        octree_level<true, false>(level, f, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                                  dyn_coff_off, 0, 0);
     else
-        octree_level<false>(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
-                            dyn_coff_off, pts_cap, dyn_pts_off);
+        octree_level<false, false>(level, f, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                                   dyn_coff_off, 0, 0);
 }
 // a batch: small workgroups, many per CU.  The grid is (frames, levels): workgroups start in linear order, so the
 // levels with the most candidates (the lowest) start first and the short ones fill the tail.  The size follows the
@@ -1402,11 +1609,11 @@ template <int kThreads, int kWavesPerSimd>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_octree_batch(OCTREE_ARGS)
 {
     if (lds_nodes)
-        octree_level<true>(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
-                           dyn_coff_off, 0, 0);
+        octree_level<true, false>(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                                  dyn_coff_off, 0, 0);
     else
-        octree_level<false>(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
-                            dyn_coff_off, 0, 0);
+        octree_level<false, false>(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                                   dyn_coff_off, 0, 0);
 }
 #undef OCTREE_ARGS
 
@@ -2012,7 +2219,7 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     int threads = !batch ? 1024 : maxcap <= 512 ? 128 : nimg * G.nlevels >= 2048 ? 256 : 512;
     if (tune.oct_threads) threads = tune.oct_threads;  // measurement hook
     const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
-    size_t dyn = coff_off + (size_t)(threads + 1) * 4;
+    size_t dyn = coff_off + (size_t)((threads > kMaxRoots ? threads : kMaxRoots) + 1) * 4;
     if (batch) {
         if (threads == 128)
             hipLaunchKernelGGL((k_octree_batch<128, 5>), dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes,
@@ -2046,7 +2253,7 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
                 } else {
                     (void)hipGetLastError();
                     pts_cap = 0;
-                    dyn = coff_off + (size_t)(threads + 1) * 4;
+                    dyn = coff_off + (size_t)((threads > kMaxRoots ? threads : kMaxRoots) + 1) * 4;
                 }
             }
         }

@@ -198,6 +198,25 @@ __device__ __forceinline__ int block_scan_excl(int v, int *total, int *lds)
     return res;
 }
 
+// The same scan with one barrier.  Every wave adds up the wave totals itself (at most 16 values: one more
+// data-parallel scan) instead of waiting for wave 0 to do it, and consecutive calls alternate between two halves of
+// lds (32 ints), so no barrier is needed before the next call writes: a wave can only be two calls ahead of another
+// after that other has passed the barrier of the call in between, i.e. has finished reading this half.  `par` is
+// the caller's call parity (any workgroup-uniform 0 / 1 variable that only these calls change).
+__device__ __forceinline__ int block_scan1(int v, int *total, int *lds, int &par)
+{
+    const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int *half = lds + (par << 4);
+    par ^= 1;
+    const int inc = wave_scan_incl(v);
+    if (lane == 63) half[wid] = inc;
+    __syncthreads();
+    const int wv = lane < nw ? half[lane] : 0;
+    const int winc = wave_scan_incl(wv);
+    *total = __builtin_amdgcn_readlane(winc, 63);
+    return inc - v + __shfl(winc - wv, wid);
+}
+
 #endif
 
 }  // namespace orbgpu
