@@ -89,9 +89,12 @@ __global__ __launch_bounds__(256) void k_halo_sides(uint8_t *__restrict__ pyr, G
 
 // Level 0 = the input image; 16 pixels per thread, 128-bit accesses when the
 // source row is 16-byte aligned.  Threads are numbered over (row, 16-pixel group).
+// As the first kernel of an extraction it also clears the call's status word (status_clear, may be null): a memset
+// node of its own adds 2-3 us to a single-frame call.
 __global__ __launch_bounds__(256) void k_pyr_copy0(const uint8_t *__restrict__ img, int stride, size_t frame_stride,
-                                                   uint8_t *__restrict__ pyr, Geom G)
+                                                   uint8_t *__restrict__ pyr, Geom G, int32_t *status_clear)
 {
+    if (status_clear && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status_clear = 0;
     const LevelGeom &g = G.lv[0];
     int f, b;
     if (!frame_block(G.nimg, &f, &b)) return;
@@ -2091,7 +2094,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr
 constexpr int kWalkMinFrames = 128;  // from here on a workgroup per frame fills the chip
 
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
-                   const Geom &G_, const XTab *xtab, const YTab *ytab, const FuseArgs *fuse)
+                   const Geom &G_, const XTab *xtab, const YTab *ytab, const FuseArgs *fuse, int32_t *status_clear)
 {
     // LDS window of one wave's 128 x 8 tile in k_pyr_walk: the largest over the levels, padded to whole 64-dword pieces
     int walk_lds_dw = 0;
@@ -2105,7 +2108,7 @@ int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, 
     Geom G = G_;
     G.nimg = nimg;
     const LevelGeom &g0 = G.lv[0];
-    hipLaunchKernelGGL(k_pyr_copy0, dim3((((g0.w + 15) / 16) * g0.h + 255) / 256, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G_);
+    hipLaunchKernelGGL(k_pyr_copy0, dim3((((g0.w + 15) / 16) * g0.h + 255) / 256, nimg), dim3(256), 0, st, d_imgs, stride, frame_stride, pyr, G_, status_clear);
     // a few frames: all levels above 0 in one launch (k_pyr_fused) when the host could tabulate the regions
     if (nimg <= 4 && G.nlevels > 1 && fuse && fuse->tab) {
         const LevelGeom &gl = G.lv[G.nlevels - 1];

@@ -30,7 +30,7 @@ void set_error(const char *fmt, ...)
 
 int launch_halo_full(hipStream_t st, int nimg, uint8_t *pyr, const Geom &G);
 int launch_pyramid(hipStream_t st, const uint8_t *d_imgs, int nimg, int stride, size_t frame_stride, uint8_t *pyr,
-                   const Geom &G, const XTab *xtab, const YTab *ytab, const FuseArgs *fuse);
+                   const Geom &G, const XTab *xtab, const YTab *ytab, const FuseArgs *fuse, int32_t *status_clear);
 int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, const uint32_t *cell_tab, uint32_t *slots,
                 int32_t *cell_counts, const LaunchTuning &tune);
 int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
@@ -795,11 +795,11 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
         if (e->prof_used < kProfSets) e->prof_used++;
     }
 #define STAGE_MARK(i) do { if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[i], st)); } while (0)
-    // the status word describes one call alone (a captured sequence clears it on every replay as well)
+    // the status word describes one call alone: the first kernel clears it (in a captured sequence on every replay)
     int32_t *status = e->status_cur;
-    if (clear_status) ORBGPU_HIP_CHECK(hipMemsetAsync(status, 0, 4, st));
     STAGE_MARK(0);
-    if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, pyr, G, (const XTab *)e->xtab.p, (const YTab *)e->ytab.p, &e->fuse)))
+    if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, pyr, G, (const XTab *)e->xtab.p, (const YTab *)e->ytab.p, &e->fuse,
+                             clear_status ? status : nullptr)))
         return rc;
     STAGE_MARK(1);
     if ((rc = launch_fast(st, nimg, pyr, G, (const uint32_t *)e->cell_tab.p, slots, cell_counts, e->tune))) return rc;

@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from orb_slam2_amd import api, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+if os.environ.get("ORBGPU_LIB_OVERRIDE"):  # a variant build (tools/build_variant.sh)
+    api.LIB_PATH = os.path.abspath(os.environ["ORBGPU_LIB_OVERRIDE"])
 seq = synth.sequence(640, 480, 4, seed=1)
 ex = api.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480)
 m = api.ORBmatcher(0.9, True)

@@ -5,7 +5,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_$tag
-timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $out -- python3 bench.py --batch 512 --streams 1 --steps 2 --warmup 1 --no-cpu --no-latency > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $out -- python3 bench.py --batch 512 --sub-batches 1 --streams 1 --steps 2 --warmup 1 --no-cpu --no-latency --no-configs > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
 python3 - $out "$@" <<'PY'
 import collections, csv, glob, re, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

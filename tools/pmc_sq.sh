@@ -6,7 +6,7 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_sq_$tag
-timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out -- python3 bench.py --batch 512 --streams 1 --steps 2 --warmup 1 --no-cpu --no-latency > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $out -- python3 bench.py --batch 512 --sub-batches 1 --streams 1 --steps 2 --warmup 1 --no-cpu --no-latency --no-configs > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
 python3 - $out <<'PY'
 import collections, csv, glob, re, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -29,7 +29,7 @@ for tag, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         traffic.setdefault(k, {})[name + "_KB_per_launch"] = sum(v) / len(v)
         traffic[k]["launches_" + tag] = len(v)
 json.dump({"batch": 512,
-           "command": "python3 bench.py --batch 512 --streams 1 --steps 3 --warmup 1 --no-cpu --no-latency (one rocprofv3 --pmc pass "
+           "command": "python3 bench.py --batch 512 --sub-batches 1 --streams 1 --steps 3 --warmup 1 --no-cpu --no-latency --no-configs (one rocprofv3 --pmc pass "
                       "per counter; one stream so that dispatches do not overlap; 512 frames per launch as in the default run)",
            "unit": "rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB; hbm_bytes = (FETCH*corr + WRITE) * 1024",
            "calibration": "k_pyr_copy0 (16 B/lane loads of a known byte count) reads 2.1x its FETCH_SIZE -> corr 2 for "
