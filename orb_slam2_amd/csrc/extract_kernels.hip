@@ -844,8 +844,9 @@ __device__ __forceinline__ int qn_buf(const QNode &n) { return (int)((uint32_t)n
 
 constexpr int kBigNode = 512;  // nodes above this many points are split by the whole workgroup
 constexpr int kQuadNode = 48;  // four nodes of at most this many points each share a wave, sixteen lanes per node
-constexpr int kBigGroup = 32;  // big nodes scattered between two barriers (four LDS cursors each)
+constexpr int kBigGroup = 16;  // big nodes scattered between two barriers (four LDS cursors and sixteen counters each)
 constexpr int kOctUnroll = 4;  // 64-point pieces a wave has in flight
+constexpr int kOctTmp = 20 * kBigGroup;  // LDS words shared by the roots' tables and the big nodes' cursors and counters
 
 // bits 16 g .. 16 g + 15 of a ballot: the lanes of sixteen-lane group g
 __device__ __forceinline__ uint32_t sub16(uint64_t b, int g)
@@ -854,20 +855,35 @@ __device__ __forceinline__ uint32_t sub16(uint64_t b, int g)
     return (h >> ((g & 1) << 4)) & 0xFFFFu;
 }
 
+// The populations of a node's four quadrants travel with the node (three of them, 21 bits each; the fourth is the
+// rest of the node's count): the pass that moves a node's points into its children also counts, for every child,
+// the points of the child's own quadrants, so a round needs no counting pass of its own.
+typedef unsigned long long QKids;
+__device__ __forceinline__ QKids pack_kids(int k0, int k1, int k2) { return (QKids)k0 | ((QKids)k1 << 21) | ((QKids)k2 << 42); }
+__device__ __forceinline__ void unpack_kids(QKids v, int cnt, int *k0, int *k1, int *k2, int *k3)
+{
+    *k0 = (int)(v & 0x1FFFFFu);
+    *k1 = (int)((v >> 21) & 0x1FFFFFu);
+    *k2 = (int)((v >> 42) & 0x1FFFFFu);
+    *k3 = cnt - *k0 - *k1 - *k2;
+}
+
 struct OctCtx {
     uint32_t *buf0, *buf1;
     QNode *nl0, *nl1;
+    QKids *kc0, *kc1;  // node_cap each: the quadrant populations of the nodes of nl0 / nl1
     int32_t *S;       // node_cap: positions (in the current list) of the nodes to split
-    int32_t *cnt4;    // 4*node_cap: per-S-entry quadrant populations
     int32_t *cbase;   // node_cap: exclusive prefix of non-empty children per S entry
-    int32_t *mark;    // node_cap: 1 where the list node is in S
-    int32_t *big;     // node_cap: S entries whose node holds more than kBigNode points
-    int *scan_lds;    // 32 ints (block_scan1)
+    int32_t *mark;    // node_cap: rank among the nodes that stay (a pass over all nodes) / 1 where the node is in S (a prefix of the sorted candidates)
+    int32_t *big;     // node_cap: S entries whose node is split by all waves
+    int *scan_lds;    // 64 ints (block_scan1, block_scan1x2)
     int *bigcur;      // 4 * kBigGroup LDS cursors
-    int par;          // call parity of block_scan1
-    int thr;          // nodes of more points than this are split by all waves (set by oct_count)
+    int *bigk;        // 16 * kBigGroup LDS counters: points per (child, quadrant of the child)
+    int *nbig;        // LDS counter of c.big (zero between passes)
+    int par;          // call parity of the workgroup scans
     __device__ __forceinline__ uint32_t *buf(int i) const { return i ? buf1 : buf0; }
     __device__ __forceinline__ QNode *nl(int i) const { return i ? nl1 : nl0; }
+    __device__ __forceinline__ QKids *kc(int i) const { return i ? kc1 : kc0; }
 };
 
 __device__ __forceinline__ int quadrant_of(uint32_t p, int midx, int midy)
@@ -875,142 +891,94 @@ __device__ __forceinline__ int quadrant_of(uint32_t p, int midx, int midy)
     return (cand_x(p) < midx ? 0 : 1) | (cand_y(p) < midy ? 0 : 2);
 }
 
-// Count quadrant populations of S[0..nS): a wave (or sixteen lanes) per small node, all waves
-// for each big node.  Returns the number of big nodes (c.big); the sums of the big nodes are
-// complete after the caller's next barrier.
-__device__ int oct_count(OctCtx &c, int cur, int nS)
+// What a split of node n needs to know about boxes: the node's centre lines (ExtractorNode::DivideNode, :606-641:
+// halfX = ceil((x1 - x0) / 2)) and those of its four children.
+struct SplitBox {
+    int midx, midy, cxl, cxr, cyt, cyb;
+    __device__ __forceinline__ SplitBox(int x0, int x1, int y0, int y1)
+    {
+        midx = x0 + ((x1 - x0 + 1) >> 1);
+        midy = y0 + ((y1 - y0 + 1) >> 1);
+        cxl = x0 + ((midx - x0 + 1) >> 1);
+        cxr = midx + ((x1 - midx + 1) >> 1);
+        cyt = y0 + ((midy - y0 + 1) >> 1);
+        cyb = midy + ((y1 - midy + 1) >> 1);
+    }
+    // 4 * quadrant + quadrant within that child
+    __device__ __forceinline__ int code(uint32_t p) const
+    {
+        const int x = cand_x(p), y = cand_y(p);
+        const int qx = x < midx ? 0 : 1, qy = y < midy ? 0 : 1;
+        const int gx = x < (qx ? cxr : cxl) ? 0 : 1, gy = y < (qy ? cyb : cyt) ? 0 : 1;
+        return ((qx | (qy << 1)) << 2) | gx | (gy << 1);
+    }
+};
+
+// Two exclusive workgroup scans behind one barrier (as block_scan1; lds: 64 ints).
+__device__ __forceinline__ void block_scan1x2(int a, int b, int *exa, int *exb, int *tota, int *totb, int *lds, int &par)
 {
-    const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6;  // nw: a power of two
-    const QNode *nl = c.nl(cur);
-    // few nodes (the early rounds): a wave per node would leave most waves idle, so every node of more than a
-    // wave's worth of points is cut into 64-point pieces that are dealt to all waves
-    const int thr = nS < 4 * nw ? 64 : kBigNode;
-    c.thr = thr;
-    int nB = 0;
-    for (int b = 0; b < nS; b += nt) {
-        const int e = b + tid;
-        const int flag = (e < nS) ? (qn_count(nl[c.S[e]]) > thr) : 0;
-        int total;
-        const int ex = block_scan1(flag, &total, c.scan_lds, c.par);
-        if (flag) {
-            c.big[nB + ex] = e;
-            c.cnt4[4 * e + 0] = 0; c.cnt4[4 * e + 1] = 0; c.cnt4[4 * e + 2] = 0; c.cnt4[4 * e + 3] = 0;  // summed by atomics below
-        }
-        nB += total;
-    }
+    const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int *half = lds + (par << 5);
+    par ^= 1;
+    const int ia = wave_scan_incl(a), ib = wave_scan_incl(b);
+    if (lane == 63) { half[wid] = ia; half[16 + wid] = ib; }
     __syncthreads();
-    // small nodes: a wave takes four S entries (nw apart, so that a handful of nodes spreads over the waves).  While
-    // none of the four holds more than kQuadNode points (the late rounds: many nodes of a few points each) sixteen
-    // lanes work on each; otherwise the wave takes them one after the other.
-    for (int base = 0; base < nS; base += 4 * nw) {
-        const int grp = lane >> 4, sl = lane & 15, eg = base + grp * nw + wid;
-        QNode ng = {};
-        int cntg = 0;
-        if (eg < nS) {
-            ng = nl[c.S[eg]];
-            cntg = qn_count(ng);
-        }
-        if (__ballot(cntg > kQuadNode) == 0ull) {
-            const uint32_t *pts = c.buf(qn_buf(ng)) + ng.start;
-            const int midx = ng.x0 + ((ng.x1 - ng.x0 + 1) >> 1), midy = ng.y0 + ((ng.y1 - ng.y0 + 1) >> 1);
-            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            for (int b = 0; __ballot(b < cntg) != 0ull; b += 16) {
-                const int i = b + sl;
-                const int q = (i < cntg) ? quadrant_of(pts[i], midx, midy) : -1;
-                c0 += __popc(sub16(__ballot(q == 0), grp));
-                c1 += __popc(sub16(__ballot(q == 1), grp));
-                c2 += __popc(sub16(__ballot(q == 2), grp));
-                c3 += __popc(sub16(__ballot(q == 3), grp));
-            }
-            if (sl == 0 && eg < nS) {
-                c.cnt4[4 * eg + 0] = c0; c.cnt4[4 * eg + 1] = c1; c.cnt4[4 * eg + 2] = c2; c.cnt4[4 * eg + 3] = c3;
-            }
-            continue;
-        }
-        for (int e = base + wid; e < min(base + 4 * nw, nS); e += nw) {
-            const QNode n = nl[c.S[e]];
-            const int cnt = qn_count(n);
-            if (cnt > thr) continue;
-            const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
-            const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            for (int b = 0; b < cnt; b += 64) {
-                const int i = b + lane;
-                const int q = (i < cnt) ? quadrant_of(pts[i], midx, midy) : -1;
-                c0 += __popcll(__ballot(q == 0));
-                c1 += __popcll(__ballot(q == 1));
-                c2 += __popcll(__ballot(q == 2));
-                c3 += __popcll(__ballot(q == 3));
-            }
-            if (lane == 0) {
-                c.cnt4[4 * e + 0] = c0; c.cnt4[4 * e + 1] = c1; c.cnt4[4 * e + 2] = c2; c.cnt4[4 * e + 3] = c3;
-            }
-        }
-    }
-    // big nodes: their 64-point pieces are numbered through and dealt round the waves.  Lane l fetches what the
-    // pieces of the l-th node of a group need and the prefix of the piece counts; a piece finds its node by one ballot
-    // over the prefixes and gets the node's data by lane reads: one chain of dependent loads per 64 nodes, not per
-    // node.  kOctUnroll pieces are fetched before the first is counted (the points of a large level are in global
-    // memory: a wave that fetched them one by one would spend its time waiting).
-    for (int g0 = 0; g0 < nB; g0 += 64) {
-        const int ng = min(64, nB - g0);
-        int me = 0, mstart = 0, mcb = 0, mmid = 0, mnc = 0;
-        if (lane < ng) {
-            me = c.big[g0 + lane];
-            const QNode n = nl[c.S[me]];
-            mstart = n.start;
-            mcb = n.count;
-            mmid = (n.x0 + ((n.x1 - n.x0 + 1) >> 1)) | ((n.y0 + ((n.y1 - n.y0 + 1) >> 1)) << 16);
-            mnc = (qn_count(n) + 63) >> 6;
-        }
-        const int mincl = wave_scan_incl(mnc), mexcl = mincl - mnc;
-        const int npieces = __builtin_amdgcn_readlane(mincl, 63);
-        // a wave's consecutive pieces mostly belong to one node: it adds up in registers and sends the sums when
-        // the node changes (thousands of atomic adds to one address would queue up in L2)
-        int cur_e = -1, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        for (int P0 = wid; P0 < npieces; P0 += kOctUnroll * nw) {
-            uint32_t pv[kOctUnroll];
-            int ev[kOctUnroll], midv[kOctUnroll];
-            bool onv[kOctUnroll];
-#pragma unroll
-            for (int u = 0; u < kOctUnroll; u++) {
-                const int P = P0 + u * nw;
-                const int bj = P < npieces ? (int)__popcll(__ballot(mincl <= P)) : 0;  // the lanes behind the group hold npieces
-                const int cb = __builtin_amdgcn_readlane(mcb, bj);
-                const int i = ((P - __builtin_amdgcn_readlane(mexcl, bj)) << 6) + lane;
-                ev[u] = P < npieces ? __builtin_amdgcn_readlane(me, bj) : -1;
-                midv[u] = __builtin_amdgcn_readlane(mmid, bj);
-                onv[u] = P < npieces && i < (cb & 0x7FFFFFFF);
-                pv[u] = onv[u] ? (c.buf((int)((uint32_t)cb >> 31)) + __builtin_amdgcn_readlane(mstart, bj))[i] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < kOctUnroll; u++) {
-                if (ev[u] != cur_e) {
-                    if (cur_e >= 0 && lane < 4) {
-                        const int v = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
-                        if (v) atomicAdd(&c.cnt4[4 * cur_e + lane], v);
-                    }
-                    cur_e = ev[u];
-                    c0 = c1 = c2 = c3 = 0;
-                }
-                const int q = onv[u] ? quadrant_of(pv[u], midv[u] & 0xFFFF, midv[u] >> 16) : -1;
-                c0 += __popcll(__ballot(q == 0));
-                c1 += __popcll(__ballot(q == 1));
-                c2 += __popcll(__ballot(q == 2));
-                c3 += __popcll(__ballot(q == 3));
-            }
-        }
-        if (cur_e >= 0 && lane < 4) {
-            const int v = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
-            if (v) atomicAdd(&c.cnt4[4 * cur_e + lane], v);
-        }
-    }
-    return nB;  // the caller's barrier completes the sums
+    const int wa = lane < nw ? half[lane] : 0, wb = lane < nw ? half[16 + lane] : 0;
+    const int sa = wave_scan_incl(wa), sb = wave_scan_incl(wb);
+    *tota = __builtin_amdgcn_readlane(sa, 63);
+    *totb = __builtin_amdgcn_readlane(sb, 63);
+    *exa = ia - a + __shfl(sa - wa, wid);
+    *exb = ib - b + __shfl(sb - wb, wid);
 }
 
-// Child q (0..3) of node n created by S entry e (ExtractorNode::DivideNode, :606-641).
+// The quadrant populations of the first nodes (the roots), list positions 0 .. size-1 of nl0: every wave takes
+// 64-point pieces of every root, adds up in registers and sends one atomic add per quadrant.  tmp: 4 * size words.
+__device__ void oct_count_roots(OctCtx &c, int size, int32_t *tmp)
+{
+    const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6;
+    for (int i = tid; i < 4 * size; i += nt) tmp[i] = 0;
+    __syncthreads();
+    int acc = 0;  // pieces before the current root: the pieces of all roots go round the waves
+    for (int r = 0; r < size; r++) {
+        const QNode n = c.nl0[r];
+        const int cnt = qn_count(n), nc = (cnt + 63) >> 6;
+        const int j0 = (wid - acc) & (nw - 1);
+        acc += nc;
+        if (j0 >= nc) continue;
+        const uint32_t *pts = c.buf(qn_buf(n)) + n.start;
+        const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int j = j0; j < nc; j += kOctUnroll * nw) {
+            uint32_t pv[kOctUnroll];
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) {
+                const int i = ((j + u * nw) << 6) + lane;
+                pv[u] = i < cnt ? pts[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kOctUnroll; u++) {
+                const int i = ((j + u * nw) << 6) + lane;
+                const int q = i < cnt ? quadrant_of(pv[u], midx, midy) : -1;
+                c0 += __popcll(__ballot(q == 0));
+                c1 += __popcll(__ballot(q == 1));
+                c2 += __popcll(__ballot(q == 2));
+                c3 += __popcll(__ballot(q == 3));
+            }
+        }
+        if (lane < 4) {
+            const int v = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
+            if (v) atomicAdd(&tmp[4 * r + lane], v);
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < size; r += nt) c.kc0[r] = pack_kids(tmp[4 * r], tmp[4 * r + 1], tmp[4 * r + 2]);
+    __syncthreads();
+}
+
+// Child q (0..3) of node n created by S entry e (ExtractorNode::DivideNode, :606-641); g0..g2: the populations of
+// the child's own first three quadrants.
 __device__ __forceinline__ void emit_child(const OctCtx &c, int cur, const QNode &n, int e, int q, int midx, int midy,
-                                           int k0, int k1, int k2, int k3, int s0, int nchild, int db)
+                                           int k0, int k1, int k2, int k3, int s0, int nchild, int db, int g0, int g1, int g2)
 {
     const int kq = q == 0 ? k0 : q == 1 ? k1 : q == 2 ? k2 : k3;
     if (kq <= 0) return;
@@ -1024,55 +992,115 @@ __device__ __forceinline__ void emit_child(const OctCtx &c, int cur, const QNode
     ch.start = s0 + (q > 0 ? k0 : 0) + (q > 1 ? k1 : 0) + (q > 2 ? k2 : 0);
     ch.count = kq | (db << 31);
     c.nl(cur ^ 1)[nchild - 1 - created] = ch;  // push_front: later creations sit nearer the front
+    c.kc(cur ^ 1)[nchild - 1 - created] = pack_kids(g0, g1, g2);
 }
 
-// Apply the split of S[0..nS) using cnt4 (nB of them listed in c.big): returns
-// the new list size, the number of children created and the number of children
-// holding more than one point.  prefix_of_sorted: S is a prefix of the sorted
-// candidates of a final pass; otherwise it is every node of more than one point.
-__device__ void oct_apply(OctCtx &c, int cur, int size, int nS, int nB, bool prefix_of_sorted, int *out_size, int *out_children, int *out_expand)
+// A pass over every node of the list (:778-887): S = the nodes of more than one point, in list order; the others
+// move behind the children-to-be in their old order.  Returns the size of S, the number of children the split of S
+// creates and how many of those hold more than one point.
+__device__ void oct_scan_all(OctCtx &c, int cur, int size, int *out_nS, int *out_children, int *out_expand)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6;
     const QNode *nl = c.nl(cur);
-    // children prefix + expandable count
-    int carry = 0, nexp = 0;
+    const QKids *kc = c.kc(cur);
+    int nS = 0, nstay = 0, nchild = 0, nexp = 0;
+    for (int b = 0; b < size; b += nt) {
+        const int i = b + tid;
+        int inS = 0, stay = 0, ne = 0, nx = 0;
+        if (i < size) {
+            const int cnt = qn_count(nl[i]);
+            inS = cnt > 1;
+            stay = !inS;
+            if (inS) {
+                int k0, k1, k2, k3;
+                unpack_kids(kc[i], cnt, &k0, &k1, &k2, &k3);
+                ne = (k0 > 0) + (k1 > 0) + (k2 > 0) + (k3 > 0);
+                nx = (k0 > 1) + (k1 > 1) + (k2 > 1) + (k3 > 1);
+            }
+        }
+        int exa, exb, ta, tb;
+        block_scan1x2(inS | (stay << 16), ne | (nx << 16), &exa, &exb, &ta, &tb, c.scan_lds, c.par);
+        if (inS) {
+            const int e = nS + (exa & 0xFFFF);
+            c.S[e] = i;
+            c.cbase[e] = nchild + (exb & 0xFFFF);
+        }
+        if (stay) c.mark[i] = nstay + (exa >> 16);
+        nS += ta & 0xFFFF; nstay += ta >> 16;
+        nchild += tb & 0xFFFF; nexp += tb >> 16;
+    }
+    __syncthreads();
+    for (int i = tid; i < size; i += nt) {
+        const QNode n = nl[i];
+        if (qn_count(n) <= 1) c.nl(cur ^ 1)[nchild + c.mark[i]] = n;  // (its quadrant populations are never looked at)
+    }
+    *out_nS = nS;
+    *out_children = nchild;
+    *out_expand = nexp;
+}
+
+// The same for S = the first nS of the sorted candidates of a final pass (:893-968).
+__device__ void oct_scan_prefix(OctCtx &c, int cur, int size, int nS, int *out_children, int *out_expand)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const QNode *nl = c.nl(cur);
+    const QKids *kc = c.kc(cur);
+    int nchild = 0, nexp = 0;
     for (int b = 0; b < nS; b += nt) {
         const int e = b + tid;
         int ne = 0, nx = 0;
         if (e < nS) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int v = c.cnt4[4 * e + q];
-                ne += v > 0;
-                nx += v > 1;
-            }
+            const int i = c.S[e];
+            int k0, k1, k2, k3;
+            unpack_kids(kc[i], qn_count(nl[i]), &k0, &k1, &k2, &k3);
+            ne = (k0 > 0) + (k1 > 0) + (k2 > 0) + (k3 > 0);
+            nx = (k0 > 1) + (k1 > 1) + (k2 > 1) + (k3 > 1);
         }
         int total;
         const int ex = block_scan1(ne | (nx << 16), &total, c.scan_lds, c.par);
-        if (e < nS) c.cbase[e] = carry + (ex & 0xFFFF);
-        carry += total & 0xFFFF;
+        if (e < nS) c.cbase[e] = nchild + (ex & 0xFFFF);
+        nchild += total & 0xFFFF;
         nexp += total >> 16;
     }
-    const int nchild = carry;
-    // survivors: list nodes not in S keep their relative order behind the children
-    if (prefix_of_sorted) {
-        for (int i = tid; i < size; i += nt) c.mark[i] = 0;
-        __syncthreads();
-        for (int e = tid; e < nS; e += nt) c.mark[c.S[e]] = 1;
-        __syncthreads();
-    }
-    carry = 0;
-    for (int b = 0; b < size; b += nt) {  // size >= 1: the barrier of this scan also publishes cbase
+    for (int i = tid; i < size; i += nt) c.mark[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < nS; e += nt) c.mark[c.S[e]] = 1;
+    __syncthreads();
+    int carry = 0;
+    for (int b = 0; b < size; b += nt) {
         const int i = b + tid;
-        const int keep = (i < size) ? (prefix_of_sorted ? c.mark[i] == 0 : qn_count(nl[i]) <= 1) : 0;
+        const int keep = (i < size) ? (c.mark[i] == 0) : 0;
         int total;
         const int ex = block_scan1(keep, &total, c.scan_lds, c.par);
-        if (keep) c.nl(cur ^ 1)[nchild + carry + ex] = nl[i];
+        if (keep) {
+            c.nl(cur ^ 1)[nchild + carry + ex] = nl[i];
+            c.kc(cur ^ 1)[nchild + carry + ex] = kc[i];
+        }
         carry += total;
     }
-    // scatter the points and emit the child nodes.  Small nodes: four S entries per wave, sixteen lanes each
-    // while all four are small, else one after the other (as in oct_count)
+    *out_children = nchild;
+    *out_expand = nexp;
+}
+
+// Split the nodes S[0..nS): their points go to the other candidate buffer, partitioned by quadrant, the child
+// nodes (with the populations of their own quadrants) to the front of the other node list.  Needs S and cbase
+// complete (a barrier since they were written); ends with a barrier.
+__device__ void oct_scatter(OctCtx &c, int cur, int nS, int nchild)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6;  // nw: a power of two
+    const QNode *nl = c.nl(cur);
+    const QKids *kc = c.kc(cur);
+    // few nodes (the early rounds): a wave per node would leave most waves idle, so every node of more than a
+    // wave's worth of points is cut into 64-point pieces that are dealt to all waves
+    const int thr = nS < 4 * nw ? 64 : kBigNode;
+    for (int e = tid; e < nS; e += nt)
+        if (qn_count(nl[c.S[e]]) > thr) c.big[atomicAdd(c.nbig, 1)] = e;
+    __syncthreads();
+    const int nB = *c.nbig;
+    // small nodes: a wave takes four S entries (nw apart, so that a handful of nodes spreads over the waves).  While
+    // none of the four holds more than kQuadNode points (the late rounds: many nodes of a few points each) sixteen
+    // lanes work on each; otherwise the wave takes them one after the other.
     for (int base = 0; base < nS; base += 4 * nw) {
         const int grp = lane >> 4, sl = lane & 15, eg = base + grp * nw + wid;
         QNode ng = {};
@@ -1085,20 +1113,24 @@ __device__ void oct_apply(OctCtx &c, int cur, int size, int nS, int nB, bool pre
             const int sb = qn_buf(ng), db = sb ^ 1;
             const uint32_t *pts = c.buf(sb) + ng.start;
             uint32_t *dst = c.buf(db);
-            const int midx = ng.x0 + ((ng.x1 - ng.x0 + 1) >> 1), midy = ng.y0 + ((ng.y1 - ng.y0 + 1) >> 1);
+            const SplitBox sbx(ng.x0, ng.x1, ng.y0, ng.y1);
             int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
-            if (eg < nS) { k0 = c.cnt4[4 * eg + 0]; k1 = c.cnt4[4 * eg + 1]; k2 = c.cnt4[4 * eg + 2]; k3 = c.cnt4[4 * eg + 3]; }
+            if (eg < nS) unpack_kids(kc[c.S[eg]], cntg, &k0, &k1, &k2, &k3);
             const int s0 = ng.start, s1 = s0 + k0, s2 = s1 + k1, s3 = s2 + k2;
             int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            int gk[12];  // populations of the first three quadrants of each child
+#pragma unroll
+            for (int k = 0; k < 12; k++) gk[k] = 0;
             const uint32_t lt = (1u << sl) - 1u;
             for (int b = 0; __ballot(b < cntg) != 0ull; b += 16) {
                 const int i = b + sl;
-                int q = -1;
+                int code = -1;
                 uint32_t p = 0;
                 if (i < cntg) {
                     p = pts[i];
-                    q = quadrant_of(p, midx, midy);
+                    code = sbx.code(p);
                 }
+                const int q = code >> 2;  // -1 stays -1
                 const uint32_t m0 = sub16(__ballot(q == 0), grp), m1 = sub16(__ballot(q == 1), grp), m2 = sub16(__ballot(q == 2), grp),
                                m3 = sub16(__ballot(q == 3), grp);
                 if (q == 0) dst[s0 + r0 + __popc(m0 & lt)] = p;
@@ -1106,73 +1138,78 @@ __device__ void oct_apply(OctCtx &c, int cur, int size, int nS, int nB, bool pre
                 else if (q == 2) dst[s2 + r2 + __popc(m2 & lt)] = p;
                 else if (q == 3) dst[s3 + r3 + __popc(m3 & lt)] = p;
                 r0 += __popc(m0); r1 += __popc(m1); r2 += __popc(m2); r3 += __popc(m3);
+#pragma unroll
+                for (int k = 0; k < 12; k++) gk[k] += __popc(sub16(__ballot(code == (k / 3) * 4 + k % 3), grp));
             }
-            if (sl < 4 && eg < nS) emit_child(c, cur, ng, eg, sl, midx, midy, k0, k1, k2, k3, s0, nchild, db);
+            if (sl < 4 && eg < nS)
+                emit_child(c, cur, ng, eg, sl, sbx.midx, sbx.midy, k0, k1, k2, k3, s0, nchild, db,
+                           sl == 0 ? gk[0] : sl == 1 ? gk[3] : sl == 2 ? gk[6] : gk[9], sl == 0 ? gk[1] : sl == 1 ? gk[4] : sl == 2 ? gk[7] : gk[10],
+                           sl == 0 ? gk[2] : sl == 1 ? gk[5] : sl == 2 ? gk[8] : gk[11]);
             continue;
         }
         for (int e = base + wid; e < min(base + 4 * nw, nS); e += nw) {
             const QNode n = nl[c.S[e]];
             const int cnt = qn_count(n), sb = qn_buf(n), db = sb ^ 1;
-            if (cnt > c.thr) continue;
+            if (cnt > thr) continue;
             const uint32_t *pts = c.buf(sb) + n.start;
             uint32_t *dst = c.buf(db);
-            const int midx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), midy = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-            const int k0 = c.cnt4[4 * e + 0], k1 = c.cnt4[4 * e + 1], k2 = c.cnt4[4 * e + 2], k3 = c.cnt4[4 * e + 3];
+            const SplitBox sbx(n.x0, n.x1, n.y0, n.y1);
+            int k0, k1, k2, k3;
+            unpack_kids(kc[c.S[e]], cnt, &k0, &k1, &k2, &k3);
             const int s0 = n.start, s1 = s0 + k0, s2 = s1 + k1, s3 = s2 + k2;
             int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            int gk[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) gk[k] = 0;
             const uint64_t lt = (1ull << lane) - 1ull;
             for (int b = 0; b < cnt; b += 64) {
                 const int i = b + lane;
-                int q = -1;
+                int code = -1;
                 uint32_t p = 0;
                 if (i < cnt) {
                     p = pts[i];
-                    q = quadrant_of(p, midx, midy);
+                    code = sbx.code(p);
                 }
+                const int q = code >> 2;
                 const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
                 if (q == 0) dst[s0 + r0 + __popcll(b0 & lt)] = p;
                 else if (q == 1) dst[s1 + r1 + __popcll(b1 & lt)] = p;
                 else if (q == 2) dst[s2 + r2 + __popcll(b2 & lt)] = p;
                 else if (q == 3) dst[s3 + r3 + __popcll(b3 & lt)] = p;
                 r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
+#pragma unroll
+                for (int k = 0; k < 12; k++) gk[k] += __popcll(__ballot(code == (k / 3) * 4 + k % 3));
             }
-            if (lane < 4) emit_child(c, cur, n, e, lane, midx, midy, k0, k1, k2, k3, s0, nchild, db);
+            if (lane < 4)
+                emit_child(c, cur, n, e, lane, sbx.midx, sbx.midy, k0, k1, k2, k3, s0, nchild, db,
+                           lane == 0 ? gk[0] : lane == 1 ? gk[3] : lane == 2 ? gk[6] : gk[9],
+                           lane == 0 ? gk[1] : lane == 1 ? gk[4] : lane == 2 ? gk[7] : gk[10],
+                           lane == 0 ? gk[2] : lane == 1 ? gk[5] : lane == 2 ? gk[8] : gk[11]);
         }
     }
-    // big nodes: their 64-point pieces go round the waves (as in oct_count); a piece claims its place in each
-    // child's range with one atomic add per non-empty quadrant
+    // big nodes: their 64-point pieces are numbered through and dealt round the waves.  Lane l fetches what the
+    // pieces of the l-th node of a group need and the prefix of the piece counts; a piece finds its node by one ballot
+    // over the prefixes and gets the node's data by lane reads.  A piece claims its place in each child's range with
+    // one atomic add per non-empty quadrant; the populations of the children's quadrants are counted by one LDS
+    // atomic per point.  kOctUnroll pieces are fetched before the first is placed (the points of a large level are in
+    // global memory: a wave that fetched them one by one would spend its time waiting).
     for (int g0 = 0; g0 < nB; g0 += kBigGroup) {
         const int ng = min(kBigGroup, nB - g0);
-        for (int i = tid; i < 4 * ng; i += nt) c.bigcur[i] = 0;
-        int me = 0x7FFFFFFF, mstart = 0, mcb = 0, mmid = 0, mk0 = 0, mk1 = 0, mk2 = 0, mnc = 0, mx = 0, my = 0;
+        for (int i = tid; i < 20 * kBigGroup; i += nt) c.bigk[i] = 0;  // counters and cursors (bigcur follows bigk)
+        int me = 0, mstart = 0, mcb = 0, mk0 = 0, mk1 = 0, mk2 = 0, mnc = 0, mx = 0, my = 0;
         if (lane < ng) {
             me = c.big[g0 + lane];
-            if (me < nS) {  // else: listed by oct_count but outside the prefix being split (no pieces)
-                const QNode n = nl[c.S[me]];
-                mstart = n.start;
-                mcb = n.count;
-                mx = (uint16_t)n.x0 | ((int)n.x1 << 16);
-                my = (uint16_t)n.y0 | ((int)n.y1 << 16);
-                mmid = (n.x0 + ((n.x1 - n.x0 + 1) >> 1)) | ((n.y0 + ((n.y1 - n.y0 + 1) >> 1)) << 16);
-                mk0 = c.cnt4[4 * me + 0]; mk1 = c.cnt4[4 * me + 1]; mk2 = c.cnt4[4 * me + 2];
-                mnc = (qn_count(n) + 63) >> 6;
-            }
+            const QNode n = nl[c.S[me]];
+            mstart = n.start;
+            mcb = n.count;
+            mx = (uint16_t)n.x0 | ((int)n.x1 << 16);
+            my = (uint16_t)n.y0 | ((int)n.y1 << 16);
+            int k3;
+            unpack_kids(kc[c.S[me]], qn_count(n), &mk0, &mk1, &mk2, &k3);
+            mnc = (qn_count(n) + 63) >> 6;
         }
         const int mincl = wave_scan_incl(mnc), mexcl = mincl - mnc;
         const int npieces = __builtin_amdgcn_readlane(mincl, 63);
-        // the child nodes: thread t makes child t & 3 of the group's node t >> 2 (every wave holds all of them)
-        for (int t0 = 0; t0 < 4 * ng; t0 += nt) {
-            const int t = t0 + tid, nd = (t >> 2) & 63;
-            const int e = __shfl(me, nd), cb = __shfl(mcb, nd), xs = __shfl(mx, nd), ys = __shfl(my, nd), mid = __shfl(mmid, nd);
-            const int k0 = __shfl(mk0, nd), k1 = __shfl(mk1, nd), k2 = __shfl(mk2, nd), s0 = __shfl(mstart, nd);
-            if (t < 4 * ng && e < nS) {
-                QNode n;
-                n.x0 = (int16_t)(xs & 0xFFFF); n.x1 = (int16_t)(xs >> 16); n.y0 = (int16_t)(ys & 0xFFFF); n.y1 = (int16_t)(ys >> 16);
-                n.start = s0; n.count = cb;
-                emit_child(c, cur, n, e, t & 3, mid & 0xFFFF, mid >> 16, k0, k1, k2, (cb & 0x7FFFFFFF) - k0 - k1 - k2, s0, nchild,
-                           (int)((uint32_t)cb >> 31) ^ 1);
-            }
-        }
         __syncthreads();
         const uint64_t lt = (1ull << lane) - 1ull;
         for (int P0 = wid; P0 < npieces; P0 += kOctUnroll * nw) {
@@ -1182,7 +1219,7 @@ __device__ void oct_apply(OctCtx &c, int cur, int size, int nS, int nB, bool pre
 #pragma unroll
             for (int u = 0; u < kOctUnroll; u++) {
                 const int P = P0 + u * nw;
-                const int bj = P < npieces ? (int)__popcll(__ballot(mincl <= P)) : 0;
+                const int bj = P < npieces ? (int)__popcll(__ballot(mincl <= P)) : 0;  // the lanes behind the group hold npieces
                 const int cb = __builtin_amdgcn_readlane(mcb, bj);
                 const int i = ((P - __builtin_amdgcn_readlane(mexcl, bj)) << 6) + lane;
                 bjv[u] = bj;
@@ -1191,9 +1228,12 @@ __device__ void oct_apply(OctCtx &c, int cur, int size, int nS, int nB, bool pre
             }
 #pragma unroll
             for (int u = 0; u < kOctUnroll; u++) {
-                const int mid = __builtin_amdgcn_readlane(mmid, bjv[u]);
-                const int q = qv[u] == 0 ? quadrant_of(pv[u], mid & 0xFFFF, mid >> 16) : -1;
+                const int xs = __builtin_amdgcn_readlane(mx, bjv[u]), ys = __builtin_amdgcn_readlane(my, bjv[u]);
+                const SplitBox sbx((int16_t)(xs & 0xFFFF), (int16_t)(xs >> 16), (int16_t)(ys & 0xFFFF), (int16_t)(ys >> 16));
+                const int code = qv[u] == 0 ? sbx.code(pv[u]) : -1;
+                const int q = code >> 2;
                 qv[u] = q;
+                if (code >= 0) atomicAdd(&c.bigk[16 * bjv[u] + code], 1);
                 const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
                 mv[u] = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;  // the lanes of this lane's quadrant
                 int base = 0;
@@ -1215,12 +1255,26 @@ __device__ void oct_apply(OctCtx &c, int cur, int size, int nS, int nB, bool pre
                 if (q >= 0) dst[at + __popcll(mv[u] & lt)] = pv[u];
             }
         }
-        if (g0 + kBigGroup < nB) __syncthreads();  // the next group clears the cursors
+        __syncthreads();
+        // the child nodes: thread t makes child t & 3 of the group's node t >> 2 (every wave holds all of them)
+        for (int t0 = 0; t0 < 4 * ng; t0 += nt) {
+            const int t = t0 + tid, nd = (t >> 2) & 63;
+            const int e = __shfl(me, nd), cb = __shfl(mcb, nd), xs = __shfl(mx, nd), ys = __shfl(my, nd);
+            const int k0 = __shfl(mk0, nd), k1 = __shfl(mk1, nd), k2 = __shfl(mk2, nd), s0 = __shfl(mstart, nd);
+            if (t < 4 * ng) {
+                QNode n;
+                n.x0 = (int16_t)(xs & 0xFFFF); n.x1 = (int16_t)(xs >> 16); n.y0 = (int16_t)(ys & 0xFFFF); n.y1 = (int16_t)(ys >> 16);
+                n.start = s0; n.count = cb;
+                const int q = t & 3;
+                const int *gkp = c.bigk + 16 * (t >> 2) + 4 * q;
+                emit_child(c, cur, n, e, q, n.x0 + ((n.x1 - n.x0 + 1) >> 1), n.y0 + ((n.y1 - n.y0 + 1) >> 1), k0, k1, k2,
+                           (cb & 0x7FFFFFFF) - k0 - k1 - k2, s0, nchild, (int)((uint32_t)cb >> 31) ^ 1, gkp[0], gkp[1], gkp[2]);
+            }
+        }
+        if (g0 + kBigGroup < nB) __syncthreads();  // the next group clears the counters
     }
     __syncthreads();
-    *out_size = nchild + (size - nS);
-    *out_children = nchild;
-    *out_expand = nexp;
+    if (tid == 0) *c.nbig = 0;  // for the next pass (its appends come after another barrier)
 }
 
 template <bool kLdsNodes, bool kLdsPts>
@@ -1239,10 +1293,11 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
     extern __shared__ __align__(16) unsigned char dyn_lds[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(dyn_lds);
     int *coff = reinterpret_cast<int *>(dyn_lds + dyn_coff_off);  // blockDim.x + 1 cell offsets of the gather
-    __shared__ int scan_lds[32];
-    __shared__ int root_cnt[kMaxRoots], root_start[kMaxRoots];
-    __shared__ int sh_a;
-    static_assert(4 * kBigGroup <= kMaxRoots, "the cursors of the big nodes reuse root_cnt");
+    __shared__ int scan_lds[64];
+    __shared__ int oct_tmp[kOctTmp];  // the roots' populations and starts; later the big nodes' counters and cursors
+    __shared__ int sh_a, sh_nbig;
+    static_assert(2 * kMaxRoots <= kOctTmp, "the roots' tables share oct_tmp");
+    int *const root_cnt = oct_tmp, *const root_start = oct_tmp + kMaxRoots;
 
     const int tid = threadIdx.x, nt = blockDim.x;
     const LevelGeom &g = G.lv[level];
@@ -1267,26 +1322,31 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
     if constexpr (kLdsNodes) {
         c.nl0 = reinterpret_cast<QNode *>(dyn_lds + (size_t)keys_cap * 8);
         c.nl1 = c.nl0 + g.node_cap;
-        int32_t *ip = reinterpret_cast<int32_t *>(c.nl1 + g.node_cap);
+        c.kc0 = reinterpret_cast<QKids *>(c.nl1 + g.node_cap);
+        c.kc1 = c.kc0 + g.node_cap;
+        int32_t *ip = reinterpret_cast<int32_t *>(c.kc1 + g.node_cap);
         c.S = ip;
-        c.cnt4 = ip + g.node_cap;
-        c.cbase = ip + 5 * g.node_cap;
-        c.mark = ip + 6 * g.node_cap;
-        c.big = ip + 7 * g.node_cap;
+        c.cbase = ip + g.node_cap;
+        c.mark = ip + 2 * g.node_cap;
+        c.big = ip + 3 * g.node_cap;
     } else {
         c.nl0 = nodes + (int64_t)f * G.node_frame + g.node_off;
         c.nl1 = c.nl0 + g.node_cap;
         int32_t *scr = scratch + ((int64_t)f * G.node_frame + g.node_off) * kScratchPerNode;  // 12 * node_cap words
         if (keys_cap == 0) keys = reinterpret_cast<unsigned long long *>(scr + 8 * g.node_cap);  // 2 * node_cap keys
-        c.S = scr;
-        c.cnt4 = scr + g.node_cap;
+        c.kc0 = reinterpret_cast<QKids *>(scr);
+        c.kc1 = c.kc0 + g.node_cap;
+        c.S = scr + 4 * g.node_cap;
         c.cbase = scr + 5 * g.node_cap;
         c.mark = scr + 6 * g.node_cap;
         c.big = scr + 7 * g.node_cap;
     }
     c.scan_lds = scan_lds;
-    c.bigcur = root_cnt;  // free once the roots exist
+    c.bigk = oct_tmp;  // free once the roots exist
+    c.bigcur = oct_tmp + 16 * kBigGroup;
+    c.nbig = &sh_nbig;
     c.par = 0;
+    if (tid == 0) sh_nbig = 0;  // (barriers follow before its first use)
     int32_t *out_count = sel_count + f * G.nlevels + level;
     uint32_t *out_sel = sel + (int64_t)f * G.total_kp_cap + g.kp_off;
 
@@ -1415,29 +1475,22 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
     __syncthreads();
     OCT_T(2);
 
+    // the roots' quadrant populations; from here on every split counts those of the nodes it creates.  (S, cbase,
+    // mark and big are one block of 4 * node_cap words, idle until the first pass.)
+    oct_count_roots(c, size, c.S);
+    OCT_T(3);
+
     // ---- subdivision rounds (:778-970) -----------------------------------------
     int cur = 0;
     bool finish = false;
     while (!finish) {
         const int prevSize = size;
-        // S = every node with more than one point, in list order
-        int nS = 0;
-        for (int b = 0; b < size; b += nt) {
-            const int i = b + tid;
-            const int flag = (i < size) ? (qn_count(c.nl(cur)[i]) > 1) : 0;
-            int total;
-            const int ex = block_scan1(flag, &total, scan_lds, c.par);
-            if (flag) c.S[nS + ex] = i;
-            nS += total;
-        }
-        __syncthreads();
+        int nS, nchild, nexp;
+        oct_scan_all(c, cur, size, &nS, &nchild, &nexp);
         if (nS == 0) break;  // nothing can be divided: size == prevSize
         OCT_T(10);
-        const int nB = oct_count(c, cur, nS);
-        __syncthreads();
-        OCT_T(11);
-        int nchild, nexp;
-        oct_apply(c, cur, size, nS, nB, false, &size, &nchild, &nexp);
+        oct_scatter(c, cur, nS, nchild);
+        size = nchild + (size - nS);
         cur ^= 1;
         OCT_T(12);
         if (size >= N || size == prevSize) break;
@@ -1496,9 +1549,6 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
                 }
                 __syncthreads();
                 OCT_T(21);
-                const int nB2 = oct_count(c, cur, nC);
-                __syncthreads();
-                OCT_T(22);
                 // first j with size + sum_{i<=j}(children_i - 1) >= N
                 // (a split never shrinks the list, so the running size crosses N at one entry only)
                 int acc = size, jstar = -1;
@@ -1507,9 +1557,10 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
                     const int e = b + tid;
                     int gain = 0;
                     if (e < nC) {
-                        gain = -1;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) gain += c.cnt4[4 * e + q] > 0;
+                        const int i = c.S[e];
+                        int k0, k1, k2, k3;
+                        unpack_kids(c.kc(cur)[i], qn_count(c.nl(cur)[i]), &k0, &k1, &k2, &k3);
+                        gain = (k0 > 0) + (k1 > 0) + (k2 > 0) + (k3 > 0) - 1;
                     }
                     int total;
                     const int ex = block_scan1(gain, &total, scan_lds, c.par);
@@ -1520,7 +1571,10 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
                 }
                 const int nS2 = jstar >= 0 ? jstar + 1 : nC;
                 OCT_T(23);
-                oct_apply(c, cur, size, nS2, nB2, true, &size, &nchild, &nexp);
+                oct_scan_prefix(c, cur, size, nS2, &nchild, &nexp);
+                __syncthreads();
+                oct_scatter(c, cur, nS2, nchild);
+                size = nchild + (size - nS2);
                 cur ^= 1;
                 OCT_T(24);
                 if (size >= N || size == prev2) { finish = true; break; }
@@ -1583,7 +1637,7 @@ __global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
     const int level = blockIdx.x, f = blockIdx.y;
     bool lds_pts = false;
     if (pts_cap > 0 && lds_nodes) {  // do this level's candidates fit the LDS left for them?
-        __shared__ int fit_scan[32];
+        __shared__ int fit_scan[64];
         const LevelGeom &g = G.lv[level];
         const int32_t *cc = cell_counts + (int64_t)f * G.total_cells + g.cell_off;
         int mine = 0, total, par = 0;

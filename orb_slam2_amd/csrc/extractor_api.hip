@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -41,6 +42,22 @@ int blur_tile_table(const Geom &G, std::vector<uint32_t> *tab);
 int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t *blur, const Geom &G, const uint32_t *sel,
                     const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
                     int capacity, int32_t *status);
+
+int wait_stream_short(hipStream_t st, int spin_us)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return ORBGPU_OK;
+        if (q != hipErrorNotReady) {
+            set_error("hipStreamQuery failed: %s", hipGetErrorString(q));
+            return ORBGPU_E_HIP;
+        }
+        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+    }
+    ORBGPU_HIP_CHECK(hipStreamSynchronize(st));
+    return ORBGPU_OK;
+}
 
 static const int8_t kPattern[1024] = {
 #include "brief_pattern.inc"
@@ -1106,7 +1123,7 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
     if (nimg >= kChunkMin && !e->profile) return extract_batch_chunked(e, imgs, nimg, w, h, stride, kps, desc, capacity, counts);
     HostExtraction X;
     if ((rc = extract_host_enqueue(e, imgs, nimg, w, h, stride, &X))) return rc;
-    ORBGPU_HIP_CHECK(hipStreamSynchronize(X.stream));
+    if ((rc = wait_stream_short(X.stream, nimg <= 2 ? 400 : 0))) return rc;
     if (*X.h_status) {
         set_error("internal capacity exceeded (status %d)", *X.h_status);
         return ORBGPU_E_CAPACITY;

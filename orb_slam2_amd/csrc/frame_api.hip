@@ -154,7 +154,10 @@ static int frame_complete(orbgpu_frame *f, const HostExtraction &X, const HostEx
 {
     int32_t hc[4] = {0, 0, 0, 0};
     if (want_nvalid) ORBGPU_HIP_CHECK(hipMemcpyAsync(hc, f->count, 16, hipMemcpyDeviceToHost, X.stream));
-    ORBGPU_HIP_CHECK(hipStreamSynchronize(X.stream));
+    {
+        const int rcw = wait_stream_short(X.stream, 400);
+        if (rcw) return rcw;
+    }
     if (*X.h_status || (XR && *XR->h_status)) {
         set_error("internal capacity exceeded (status %d)", *X.h_status ? *X.h_status : *XR->h_status);
         return ORBGPU_E_CAPACITY;

@@ -123,6 +123,11 @@ int extract_host_enqueue(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
 int extract_host_begin(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h, int32_t stride,
                        HostExtraction *X);
 
+// Wait for a stream whose work is a single short call (a frame or two: ~0.1 ms).  The blocking wait returns 10-15 us
+// after the GPU is done; asking for the stream's state in a loop returns within a microsecond or two.  After spin_us
+// the call falls back to the blocking wait, so a long batch does not burn a core.
+int wait_stream_short(hipStream_t st, int spin_us);
+
 // Grids are (blocks, frames).  Workgroups are dealt to the 8 XCDs round-robin in
 // linear order; for batches of 8 or more frames the grid is (8 * blocks, frame
 // groups of 8) instead, so that all blocks of a frame run on one XCD and share
@@ -200,13 +205,13 @@ __device__ __forceinline__ int block_scan_excl(int v, int *total, int *lds)
 
 // The same scan with one barrier.  Every wave adds up the wave totals itself (at most 16 values: one more
 // data-parallel scan) instead of waiting for wave 0 to do it, and consecutive calls alternate between two halves of
-// lds (32 ints), so no barrier is needed before the next call writes: a wave can only be two calls ahead of another
+// lds (64 ints: 32 apart), so no barrier is needed before the next call writes: a wave can only be two calls ahead of another
 // after that other has passed the barrier of the call in between, i.e. has finished reading this half.  `par` is
 // the caller's call parity (any workgroup-uniform 0 / 1 variable that only these calls change).
 __device__ __forceinline__ int block_scan1(int v, int *total, int *lds, int &par)
 {
     const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int *half = lds + (par << 4);
+    int *half = lds + (par << 5);
     par ^= 1;
     const int inc = wave_scan_incl(v);
     if (lane == 63) half[wid] = inc;
