@@ -1041,9 +1041,13 @@ int orbgpu::extract_host_enqueue(orbgpu_extractor *e, const uint8_t *const *imgs
     X->d_kps = d_k; X->d_desc = d_d; X->d_counts = d_c;
     e->status_cur = d_c + nimg;
     const size_t block_bytes = (size_t)nimg * cap * (sizeof(orbgpu_keypoint) + 32) + (size_t)nimg * 4 + 4;
+    // One or two frames: the first kernel reads the page-locked staging block in place (it is mapped into the device's
+    // address space; the kernel streams the image over PCIe as fast as a copy would, and the copy's own launch and
+    // the second pass over the image are saved).  Larger batches upload first: their kernels start on resident data.
+    const bool in_place = nimg <= 2;
     auto enqueue = [&]() -> int {
-        ORBGPU_HIP_CHECK(hipMemcpyAsync(e->st_img.p, h_in, (size_t)nimg * w * h, hipMemcpyHostToDevice, st));
-        int r = enqueue_extract(e, 0, (const uint8_t *)e->st_img.p, nimg, w, (size_t)w * h, d_k, d_d, cap, d_c, true);
+        if (!in_place) ORBGPU_HIP_CHECK(hipMemcpyAsync(e->st_img.p, h_in, (size_t)nimg * w * h, hipMemcpyHostToDevice, st));
+        int r = enqueue_extract(e, 0, in_place ? h_in : (const uint8_t *)e->st_img.p, nimg, w, (size_t)w * h, d_k, d_d, cap, d_c, true);
         if (r) return r;
         ORBGPU_HIP_CHECK(hipMemcpyAsync(hp, d_k, block_bytes, hipMemcpyDeviceToHost, st));
         return ORBGPU_OK;
