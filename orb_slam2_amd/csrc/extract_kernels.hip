@@ -1632,9 +1632,12 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
         int32_t *scratch, uint32_t *__restrict__ sel, int32_t *__restrict__ sel_count, int32_t *__restrict__ cand_count,     \
         int32_t *__restrict__ status, int keys_cap, int lds_nodes, int dyn_coff_off, int pts_cap, int dyn_pts_off
 // one frame: a few 1024-thread workgroups, each with most of a CU's LDS (candidate buffers included)
-__global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
+__device__ __forceinline__ void octree_single(const int level, const int f, const Geom &G, const uint32_t *__restrict__ slots,
+                                              const int32_t *__restrict__ cell_counts, uint32_t *cand, QNode *nodes, int32_t *scratch,
+                                              uint32_t *__restrict__ sel, int32_t *__restrict__ sel_count,
+                                              int32_t *__restrict__ cand_count, int32_t *__restrict__ status, int keys_cap,
+                                              int lds_nodes, int dyn_coff_off, int pts_cap, int dyn_pts_off)
 {
-    const int level = blockIdx.x, f = blockIdx.y;
     bool lds_pts = false;
     if (pts_cap > 0 && lds_nodes) {  // do this level's candidates fit the LDS left for them?
         __shared__ int fit_scan[64];
@@ -1655,6 +1658,11 @@ __global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
         octree_level<false, false>(level, f, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
                                    dyn_coff_off, 0, 0);
 }
+__global__ __launch_bounds__(1024) void k_octree(OCTREE_ARGS)
+{
+    octree_single(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes,
+                  dyn_coff_off, pts_cap, dyn_pts_off);
+}
 // a batch: small workgroups, many per CU.  The grid is (frames, levels): workgroups start in linear order, so the
 // levels with the most candidates (the lowest) start first and the short ones fill the tail.  The size follows the
 // work of a level: 128 threads (LDS lets nine share a CU: five waves per SIMD, hence the register budget) for
@@ -1672,7 +1680,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void k_octree_batch(OCTREE
         octree_level<false, false>(blockIdx.y, blockIdx.x, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
                                    dyn_coff_off, 0, 0);
 }
-#undef OCTREE_ARGS
 
 // ---------------------------------------------------------------------------
 // GaussianBlur 7x7, sigma 2, 8-bit fixed point (called at :1502).  All levels
@@ -1715,9 +1722,8 @@ __device__ __forceinline__ uint32_t u4_at(const uint4 &v, int q) { return q == 0
 // writes four packed dwords.  EDGE: the tile touches the left or the right edge of the level.
 template <bool EDGE>
 __device__ __forceinline__ void blur_rows(const uint8_t *__restrict__ in, const LevelGeom &g, int tx0, int ty0, uint32_t klo,
-                                          uint32_t khi, uint32_t *hpair)
+                                          uint32_t khi, uint32_t *hpair, const int tid)
 {
-    const int tid = threadIdx.x;
     const int xlim = (g.w + 15) & ~3, ylim = g.h + 2;
     constexpr int CG = kBW / 4;  // column groups of a tile row
     const bool left_edge = tx0 == 0, right_edge = g.w < tx0 + kBW + 4;  // uniform
@@ -1792,16 +1798,17 @@ __device__ __forceinline__ void blur_rows(const uint8_t *__restrict__ in, const 
 
 // One wave per 64 x 32 tile: narrow tiles waste few lanes on the level widths, and the 19 x 16 horizontal tasks
 // fill five passes of the wave almost completely.
-__global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G,
-                                                      const uint32_t *__restrict__ tile_tab)
+constexpr int kBlurLdsWords = (kBH + 6) / 2 * kBW;  // LDS of one tile (one wave)
+// The tile tt (level | tile column << 8 | tile row << 20) of frame f by one wave; tid: the lane; hpair: the wave's
+// kBlurLdsWords of LDS.  Every wave of the workgroup must call it together (one barrier inside); active = false
+// for a wave that only keeps the others company.
+__device__ __forceinline__ void blur_tile(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, const Geom &G, const int f,
+                                          const uint32_t tt, uint32_t *hpair, const int tid, const bool active)
 {
-    // horizontal sums (16 bit) of source rows 2i and 2i+1 share a dword: hpair[i][x] = h[2i][x] | h[2i+1][x] << 16
-    __shared__ __align__(16) uint32_t hpair[(kBH + 6) / 2 * kBW];
-    int f, t;
-    if (!frame_block(G.nimg, &f, &t)) return;
-    const int tid = threadIdx.x;
-    // the host tabulates the tiles: level | tile column << 8 | tile row << 20 (no searches or divisions here)
-    const uint32_t tt = tile_tab[t];
+    if (!active) {
+        __syncthreads();
+        return;
+    }
     const LevelGeom &g = G.lv[tt & 0xFF];
     const int ty0 = (int)(tt >> 20) * kBH, tx0 = (int)((tt >> 8) & 0xFFF) * kBW;
     // taps (:1487, cv::GaussianBlur 7x7 sigma 2 in 8-bit fixed point) as byte / 16-bit dot-product operands
@@ -1811,8 +1818,8 @@ __global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict
     // The halo rows hold the reflect-101 image of the interior (the producers write them); the three reflected
     // columns on either side are formed here from the row's own interior, in the tiles that touch an edge (their
     // own copy of the loop: the other tiles run without the checks).
-    if (tx0 == 0 || g.w < tx0 + kBW + 4) blur_rows<true>(in, g, tx0, ty0, klo, khi, hpair);
-    else blur_rows<false>(in, g, tx0, ty0, klo, khi, hpair);
+    if (tx0 == 0 || g.w < tx0 + kBW + 4) blur_rows<true>(in, g, tx0, ty0, klo, khi, hpair, tid);
+    else blur_rows<false>(in, g, tx0, ty0, klo, khi, hpair, tid);
     __syncthreads();
     // vertical pass: thread = 4 columns x 8 rows; output row y0+rr sums source rows y0+rr .. y0+rr+6,
     // i.e. four row pairs with the taps aligned for an even or an odd first row
@@ -1850,6 +1857,37 @@ __global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict
         dst[1] = make_uint4(rows8[4], rows8[5], rows8[6], rows8[7]);
     }
 }
+
+__global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom G,
+                                                      const uint32_t *__restrict__ tile_tab)
+{
+    // horizontal sums (16 bit) of source rows 2i and 2i+1 share a dword: hpair[i][x] = h[2i][x] | h[2i+1][x] << 16
+    __shared__ __align__(16) uint32_t hpair[kBlurLdsWords];
+    int f, t;
+    if (!frame_block(G.nimg, &f, &t)) return;
+    // the host tabulates the tiles: level | tile column << 8 | tile row << 20 (no searches or divisions here)
+    blur_tile(pyr, blur, G, f, tile_tab[t], hpair, threadIdx.x, true);
+}
+
+// One or two frames: the quadtree's few long workgroups (blockIdx.x < levels) and the blur's tiles (sixteen per
+// workgroup, a wave each, in the dynamic LDS) in one launch.  Both depend on the pyramid and FAST only; as two
+// launches on one stream the blur's few microseconds come on top of the quadtree's, and a second stream costs
+// more than that in hand-overs.
+__global__ __launch_bounds__(1024) void k_octree_blur(OCTREE_ARGS, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                                      const uint32_t *__restrict__ tile_tab, int ntiles)
+{
+    if ((int)blockIdx.x < G.nlevels) {
+        octree_single(blockIdx.x, blockIdx.y, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap,
+                      lds_nodes, dyn_coff_off, pts_cap, dyn_pts_off);
+        return;
+    }
+    extern __shared__ __align__(16) unsigned char dyn_lds_blur[];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = ((int)blockIdx.x - G.nlevels) * 16 + wv;
+    uint32_t *hpair = reinterpret_cast<uint32_t *>(dyn_lds_blur) + wv * kBlurLdsWords;
+    blur_tile(pyr, blur, G, blockIdx.y, t < ntiles ? tile_tab[t] : 0u, hpair, threadIdx.x & 63, t < ntiles);
+}
+#undef OCTREE_ARGS
 
 // ---------------------------------------------------------------------------
 // Orientation (IC_Angle, :85-130), steered BRIEF (:142-191) and the final
@@ -2262,8 +2300,9 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
 
 int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
                   QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status,
-                  const LaunchTuning &tune)
+                  const LaunchTuning &tune, const BlurWork *with_blur, bool *blur_done)
 {
+    if (blur_done) *blur_done = false;
     int maxcap = 0;
     for (int l = 0; l < G.nlevels; l++) maxcap = G.lv[l].node_cap > maxcap ? G.lv[l].node_cap : maxcap;
     int keys_cap = 2;
@@ -2297,25 +2336,39 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
         pts_cap &= ~3;
         if (pts_cap < 256) pts_cap = 0;
         if (pts_cap) dyn = pts_off + (size_t)pts_cap * 8;
-        // dynamic LDS beyond 64 KiB is asked for once per device (the attribute belongs to the device's copy of the
-        // kernel); handles on several devices, or the two extractors of a stereo build on two host threads, may get here
-        // at the same time
+        // one or two frames: the blur's tiles ride in the same launch (sixteen waves per workgroup, a tile's LDS each)
+        bool fuse_blur = with_blur && blur_done && threads == 1024 && with_blur->ntiles > 0;
+        const size_t blur_lds = (size_t)16 * kBlurLdsWords * 4;
+        if (fuse_blur && blur_lds > dyn) dyn = blur_lds;
+        // dynamic LDS beyond 64 KiB is asked for once per device and kernel (the attribute belongs to the device's copy
+        // of the kernel); handles on several devices, or the two extractors of a stereo build on two host threads, may
+        // get here at the same time
         if (dyn > 64 * 1024) {
-            static std::atomic<bool> granted[64];
+            static std::atomic<bool> granted[2][64];
             int dev = -1;
             const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
-            if (!(known && granted[dev].load(std::memory_order_acquire))) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget + 8192) == hipSuccess) {
-                    if (known) granted[dev].store(true, std::memory_order_release);
+            std::atomic<bool> *flag = known ? &granted[fuse_blur ? 1 : 0][dev] : nullptr;
+            if (!(flag && flag->load(std::memory_order_acquire))) {
+                const void *fn = fuse_blur ? reinterpret_cast<const void *>(k_octree_blur) : reinterpret_cast<const void *>(k_octree);
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget + 8192) == hipSuccess) {
+                    if (flag) flag->store(true, std::memory_order_release);
                 } else {
                     (void)hipGetLastError();
                     pts_cap = 0;
+                    fuse_blur = false;
                     dyn = coff_off + (size_t)((threads > kMaxRoots ? threads : kMaxRoots) + 1) * 4;
                 }
             }
         }
-        hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch, sel,
-                           sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, pts_cap, (int)pts_off);
+        if (fuse_blur) {
+            hipLaunchKernelGGL(k_octree_blur, dim3(G.nlevels + (with_blur->ntiles + 15) / 16, nimg), dim3(threads), dyn, st, G, slots, cell_counts,
+                               cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, pts_cap, (int)pts_off,
+                               with_blur->pyr, with_blur->blur, with_blur->tile_tab, with_blur->ntiles);
+            *blur_done = true;
+        } else {
+            hipLaunchKernelGGL(k_octree, dim3(G.nlevels, nimg), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes, scratch, sel,
+                               sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, pts_cap, (int)pts_off);
+        }
     }
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;

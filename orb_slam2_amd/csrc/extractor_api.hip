@@ -36,7 +36,7 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
                 int32_t *cell_counts, const LaunchTuning &tune);
 int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots, const int32_t *cell_counts, uint32_t *cand,
                   QNode *nodes, int32_t *scratch, uint32_t *sel, int32_t *sel_count, int32_t *cand_count, int32_t *status,
-                  const LaunchTuning &tune);
+                  const LaunchTuning &tune, const BlurWork *with_blur, bool *blur_done);
 int launch_blur(hipStream_t st, int nimg, const uint8_t *pyr, uint8_t *blur, const Geom &G, const uint32_t *tile_tab, int ntiles);
 int blur_tile_table(const Geom &G, std::vector<uint32_t> *tab);
 int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t *blur, const Geom &G, const uint32_t *sel,
@@ -835,11 +835,18 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     for (int l = 0; l < G.nlevels; l++) maxcap = G.lv[l].node_cap > maxcap ? G.lv[l].node_cap : maxcap;
     const bool blur_second = e->tune.schedule == 1 || (e->tune.schedule == 0 && maxcap > 512);
     e->last_schedule = serial ? 0 : blur_second ? 2 : 1;
-    if (serial) {
+    if (serial && !ev && !e->serialize) {
+        // one launch for both (unless the stages are being timed one by one)
+        const BlurWork bw = {pyr, blur, (const uint32_t *)e->blur_tab.p, e->blur_tiles};
+        bool blur_done = false;
+        if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune, &bw, &blur_done)))
+            return rc;
+        if (!blur_done && (rc = launch_blur(st, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
+    } else if (serial) {
         if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], st));
         if ((rc = launch_blur(st, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
         if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], st));
-        if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune)))
+        if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune, nullptr, nullptr)))
             return rc;
         STAGE_MARK(3);
     } else if (blur_second) {
@@ -852,7 +859,7 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
         if ((rc = launch_blur(ax, nimg, pyr, blur, G, (const uint32_t *)e->blur_tab.p, e->blur_tiles))) return rc;
         if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
         ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));
-        if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune)))
+        if ((rc = launch_octree(st, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune, nullptr, nullptr)))
             return rc;
         STAGE_MARK(3);
         ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
@@ -861,7 +868,7 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
         ORBGPU_HIP_CHECK(hipEventRecord(e->ev_fork, st));
         ORBGPU_HIP_CHECK(hipStreamWaitEvent(ax, e->ev_fork, 0));
         if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[5], ax));
-        if ((rc = launch_octree(ax, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune)))
+        if ((rc = launch_octree(ax, nimg, G, slots, cell_counts, cand, nodes, scratch, sel, sel_count, cand_count, status, e->tune, nullptr, nullptr)))
             return rc;
         if (ev) ORBGPU_HIP_CHECK(hipEventRecord(ev[6], ax));
         ORBGPU_HIP_CHECK(hipEventRecord(e->ev_join, ax));

@@ -105,6 +105,14 @@ void set_error(const char *fmt, ...);
 // (never on a launch path): ORBGPU_FAST_QUEUE_CAP caps the FAST kernel's survivor queue (0: by geometry),
 // ORBGPU_OCT_THREADS = 128 / 256 / 512 forces the batched quadtree's workgroup size (0: by geometry).
 // ORBGPU_SCHEDULE = 1 / 2 forces the blur / the quadtree onto the second stream (0: by geometry).
+// The blur of a launch, for the quadtree launcher to take along (one or two frames).
+struct BlurWork {
+    const uint8_t *pyr;
+    uint8_t *blur;
+    const uint32_t *tile_tab;
+    int ntiles;
+};
+
 struct LaunchTuning { int fast_queue_cap = 0, oct_threads = 0, schedule = 0; };
 
 // Where the host-image path of an extractor handle leaves its results (extractor_api.hip).
