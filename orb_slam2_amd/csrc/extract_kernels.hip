@@ -2321,7 +2321,7 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
             hipLaunchKernelGGL((k_octree_batch<128, 5>), dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes,
                                scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, 0, 0);
         else if (threads == 256)
-            hipLaunchKernelGGL((k_octree_batch<256, 8>), dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes,
+            hipLaunchKernelGGL((k_octree_batch<256, 4>), dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes,
                                scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, 0, 0);
         else
             hipLaunchKernelGGL((k_octree_batch<512, 4>), dim3(nimg, G.nlevels), dim3(threads), dyn, st, G, slots, cell_counts, cand, nodes,
