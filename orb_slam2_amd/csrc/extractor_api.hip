@@ -1,5 +1,6 @@
 // C-ABI entry points of the extractor half of liborbgpu (see include/orbgpu.h).
 // Reference lines are relative to /root/reference/src/ORB_SLAM2/.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -42,6 +43,41 @@ int blur_tile_table(const Geom &G, std::vector<uint32_t> *tab);
 int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t *blur, const Geom &G, const uint32_t *sel,
                     const int32_t *sel_count, const int8_t *pattern, orbgpu_keypoint *kps, uint8_t *desc, int32_t *counts,
                     int capacity, int32_t *status);
+
+namespace {
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)();
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+void roctx_resolve()
+{
+    const char *on = getenv("ORBGPU_ROCTX");
+    if (!on || atoi(on) == 0) return;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        void *hnd = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!hnd) continue;
+        roctx_push_fn push = (roctx_push_fn)dlsym(hnd, "roctxRangePushA");
+        roctx_pop_fn pop = (roctx_pop_fn)dlsym(hnd, "roctxRangePop");
+        if (push && pop) {
+            g_roctx_push = push;
+            g_roctx_pop = pop;
+            return;
+        }
+    }
+}
+}  // namespace
+
+TraceRange::TraceRange(const char *name)
+{
+    std::call_once(g_roctx_once, roctx_resolve);
+    on_ = g_roctx_push != nullptr;
+    if (on_) (void)g_roctx_push(name);
+}
+TraceRange::~TraceRange()
+{
+    if (on_) (void)g_roctx_pop();
+}
 
 int wait_stream_short(hipStream_t st, int spin_us)
 {
@@ -815,11 +851,18 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     // the status word describes one call alone: the first kernel clears it (in a captured sequence on every replay)
     int32_t *status = e->status_cur;
     STAGE_MARK(0);
+    TraceRange tr_all("orbgpu.extract");
+    {
+    TraceRange tr("orbgpu.pyramid");
     if ((rc = launch_pyramid(st, d_imgs, nimg, stride, frame_stride, pyr, G, (const XTab *)e->xtab.p, (const YTab *)e->ytab.p, &e->fuse,
                              clear_status ? status : nullptr)))
         return rc;
+    }
     STAGE_MARK(1);
+    {
+    TraceRange tr("orbgpu.fast_cells");
     if ((rc = launch_fast(st, nimg, pyr, G, (const uint32_t *)e->cell_tab.p, slots, cell_counts, e->tune))) return rc;
+    }
     STAGE_MARK(2);
     // fork: the blur depends on the pyramid only, the quadtree on FAST.  The quadtree is a few long, latency-bound
     // workgroups, the blur keeps every SIMD busy: the quadtree goes first, onto a stream of its own, and the blur
@@ -835,6 +878,8 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
     for (int l = 0; l < G.nlevels; l++) maxcap = G.lv[l].node_cap > maxcap ? G.lv[l].node_cap : maxcap;
     const bool blur_second = e->tune.schedule == 1 || (e->tune.schedule == 0 && maxcap > 512);
     e->last_schedule = serial ? 0 : blur_second ? 2 : 1;
+    {
+    TraceRange tr("orbgpu.quadtree+blur");
     if (serial && !ev && !e->serialize) {
         // one launch for both (unless the stages are being timed one by one)
         const BlurWork bw = {pyr, blur, (const uint32_t *)e->blur_tab.p, e->blur_tiles};
@@ -876,6 +921,8 @@ static int enqueue_extract(orbgpu_extractor *e, int frame0, const uint8_t *d_img
         STAGE_MARK(3);
         ORBGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));  // join
     }
+    }
+    TraceRange tr_desc("orbgpu.describe");
     if ((rc = launch_describe(st, nimg, pyr, blur, G, sel, sel_count, (const int8_t *)e->pattern.p, d_kps, d_desc, d_counts, capacity,
                               status)))
         return rc;

@@ -275,6 +275,7 @@ int orbgpu_descriptor_distance(const uint8_t *a, const uint8_t *b)
 int orbgpu_hamming_bruteforce_device(orbgpu_matcher *m, const uint8_t *d_Q, int32_t nq, const uint8_t *d_T, int32_t nt,
                                      int32_t *d_best_idx, int32_t *d_best_d, int32_t *d_second_d)
 {
+    TraceRange trace_range("orbgpu.hamming_bruteforce");
     if (!m || nq < 0 || nt < 0 || (nq > 0 && (!d_Q || !d_best_idx || !d_best_d || !d_second_d)) || (nt > 0 && !d_T)) {
         set_error("orbgpu_hamming_bruteforce: invalid argument");
         return ORBGPU_E_INVALID;
@@ -410,6 +411,7 @@ int orbgpu_search_by_projection_batch_device(orbgpu_matcher *m, int32_t mode, in
                                              const uint8_t *d_occupied, int32_t *d_assign, int32_t th_dist, float nnratio,
                                              int32_t check_orientation, int32_t *d_nmatches)
 {
+    TraceRange trace_range("orbgpu.search_by_projection");
     if (!m || mode < 0 || mode > 2 || !d_q || !d_qdesc || !d_nq || !d_kps2 || !d_desc2 || !d_n2 || !bounds4_host || !d_assign ||
         !d_nmatches) {
         set_error("orbgpu_search_by_projection_batch_device: invalid argument");
@@ -535,6 +537,7 @@ int orbgpu_search_by_projection(orbgpu_matcher *m, int32_t mode, const orbgpu_wq
                                 const float *bounds4, const uint8_t *occupied, int32_t *assign, int32_t th_dist, float nnratio,
                                 int32_t check_orientation, int32_t *nmatches)
 {
+    TraceRange trace_range("orbgpu.search_by_projection");
     if (!m || mode < 0 || mode > 2 || nq < 0 || n2 < 0 || (nq > 0 && (!q || !qdesc)) || (n2 > 0 && (!kps2 || !desc2 || !assign)) ||
         !bounds4 || !nmatches) {
         set_error("orbgpu_search_by_projection: invalid argument");
@@ -771,6 +774,7 @@ int orbgpu_search_for_initialization(orbgpu_matcher *m, const orbgpu_keypoint *k
                                      float *prev_matched_xy, int32_t *matches12, int32_t window_size, float nnratio,
                                      int32_t check_orientation, int32_t *nmatches)
 {
+    TraceRange trace_range("orbgpu.search_for_initialization");
     if (!m || n1 < 0 || n2 < 0 || (n1 > 0 && (!kps1 || !desc1 || !prev_matched_xy || !matches12)) || (n2 > 0 && (!kps2 || !desc2)) ||
         !bounds4 || !nmatches) {
         set_error("orbgpu_search_for_initialization: invalid argument");
@@ -808,6 +812,7 @@ int orbgpu_search_for_initialization_batch_device(orbgpu_matcher *m, int32_t npa
                                                   int32_t capacity2, const float *bounds4_host, int32_t window_size, float nnratio,
                                                   int32_t check_orientation, int32_t *d_matches12, int32_t *d_nmatches)
 {
+    TraceRange trace_range("orbgpu.search_for_initialization");
     if (!m || npairs < 1 || capacity1 < 1 || capacity2 < 1 || !d_kps1 || !d_desc1 || !d_n1 || !d_kps2 || !d_desc2 || !d_n2 ||
         !bounds4_host || !d_matches12 || !d_nmatches) {
         set_error("orbgpu_search_for_initialization_batch_device: invalid argument");
@@ -843,6 +848,7 @@ int orbgpu_stereo_match(orbgpu_matcher *m, orbgpu_extractor *left, orbgpu_extrac
                         const orbgpu_keypoint *kpsL, const uint8_t *descL, int32_t nL, const orbgpu_keypoint *kpsR,
                         const uint8_t *descR, int32_t nR, float bf, float b, float *uRight, float *depth, int32_t *nvalid)
 {
+    TraceRange trace_range("orbgpu.stereo_match");
     if (!m || !left || !right || nL < 0 || nR < 0 || (nL > 0 && (!kpsL || !descL || !uRight || !depth)) ||
         (nR > 0 && (!kpsR || !descR)) || !nvalid || !(b > 0)) {
         set_error("orbgpu_stereo_match: invalid argument");
@@ -952,6 +958,7 @@ int orbgpu_stereo_match_batch_device(orbgpu_matcher *m, orbgpu_extractor *left, 
                                      const orbgpu_keypoint *d_kpsR, const uint8_t *d_descR, const int32_t *d_nR, int32_t capR,
                                      float bf, float b, float *d_uRight, float *d_depth, int32_t *d_nvalid)
 {
+    TraceRange trace_range("orbgpu.stereo_match");
     if (!m || !left || !right || left == right || npairs < 1 || capL < 1 || capR < 1 || !d_kpsL || !d_descL || !d_nL || !d_kpsR ||
         !d_descR || !d_nR || !d_uRight || !d_depth || !d_nvalid || !(b > 0)) {
         set_error("orbgpu_stereo_match_batch_device: invalid argument");

@@ -131,6 +131,19 @@ int extract_host_enqueue(orbgpu_extractor *e, const uint8_t *const *imgs, int32_
 int extract_host_begin(orbgpu_extractor *e, const uint8_t *const *imgs, int32_t nimg, int32_t w, int32_t h, int32_t stride,
                        HostExtraction *X);
 
+// Named ranges for tracing tools (rocprofv3 --marker-trace): with ORBGPU_ROCTX=1 in the environment when the library
+// first needs them, roctxRangePushA / roctxRangePop are looked up in librocprofiler-sdk-roctx.so (or libroctx64.so)
+// and every stage's enqueue is bracketed; otherwise a range is two predictable branches.  The ranges mark where the
+// host enqueues a stage (the kernels run later on the stream; the tools correlate them by their launch calls).
+struct TraceRange {
+    explicit TraceRange(const char *name);
+    ~TraceRange();
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+private:
+    bool on_;
+};
+
 // Wait for a stream whose work is a single short call (a frame or two: ~0.1 ms).  The blocking wait returns 10-15 us
 // after the GPU is done; asking for the stream's state in a loop returns within a microsecond or two.  After spin_us
 // the call falls back to the blocking wait, so a long batch does not burn a core.

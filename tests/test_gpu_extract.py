@@ -580,3 +580,29 @@ def test_fast_dense_path_when_the_survivor_queue_overflows(oracle, monkeypatch):
     for i in range(24):
         k1, d1 = ref(seq[i])
         assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1), "frame %d" % i
+
+
+def test_trace_ranges_leave_the_results_alone(tmp_path):
+    """ORBGPU_ROCTX=1 (roctx ranges around every stage's enqueue, looked up at run time) changes nothing but the
+    trace: a child process extracts and matches with the ranges on, the parent without."""
+    import os
+    import subprocess
+    import sys
+    from orb_slam2_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "from orb_slam2_amd import api, synth\n"
+            "seq = synth.sequence(320, 240, 2, seed=5)\n"
+            "ex = api.ORBextractor(500, 1.2, 6, 20, 7, max_width=320, max_height=240)\n"
+            "k, d = ex(seq[0])\n"
+            "np.save(%r, d)\n"
+            "print(len(k))\n") % (root, str(tmp_path / "d.npy"))
+    env = dict(os.environ, ORBGPU_ROCTX="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr
+    seq = synth.sequence(320, 240, 2, seed=5)
+    ex = api.ORBextractor(500, 1.2, 6, 20, 7, max_width=320, max_height=240)
+    k, d = ex(seq[0])
+    assert int(out.stdout.split()[-1]) == len(k) > 50
+    assert np.array_equal(np.load(tmp_path / "d.npy"), d)
