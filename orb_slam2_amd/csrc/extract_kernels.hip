@@ -1954,10 +1954,12 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 
 struct __attribute__((aligned(4))) DwordPair { uint32_t lo, hi; };  // one 64-bit load at 32-bit alignment
 
-constexpr int kDescGroup = 8;   // keypoint slots per wave
+constexpr int kDescGroup = 8;   // keypoint slots per wave in batches (a few frames: kDescGroupFew, shorter chains on more waves)
+constexpr int kDescGroupFew = 2;
 constexpr int kBR = 18;         // largest rotated pattern coordinate: round(hypot(13, 13))
 constexpr int kBPitch = 40;     // bytes per staged row of the blurred patch: 37 + up to 3 of alignment
 
+template <int kGroup>
 __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, Geom G,
                                                   const uint32_t *__restrict__ sel, const int32_t *__restrict__ sel_count,
                                                   const int8_t *__restrict__ pattern, orbgpu_keypoint *__restrict__ kps,
@@ -1966,7 +1968,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr
 {
     // One wave per workgroup (waves never cooperate here; four-wave workgroups take the same time alone but pack
     // worse beside the other streams' kernels: 303 k against 309 k frames/s for the whole step).
-    // A wave owns kDescGroup consecutive keypoint slots.  Stage A: intensity
+    // A wave owns kGroup consecutive keypoint slots.  Stage A: intensity
     // centroid of each (aligned 32-bit loads, dot products against per-lane
     // weights).  Stage B: lane j turns the moments of keypoint j into angle,
     // sine and cosine -- once for the whole group.  Stage C: the blurred patch
@@ -1976,7 +1978,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr
     if (!frame_block(G.nimg, &f, &blk)) return;
     const int lane = lane_id();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot0 = (blk * 1 + wv) * kDescGroup;
+    const int slot0 = (blk * 1 + wv) * kGroup;
     if (slot0 >= G.total_kp_cap) return;
     const int32_t *sc = sel_count + f * G.nlevels;
 #ifdef ORBGPU_STAMPS
@@ -1997,17 +1999,17 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr
         int any = slot0 == 0;  // the wave of slot 0 also writes the frame's count
 #pragma unroll
         for (int k = 0; k < ORBGPU_MAX_LEVELS; k++)
-            any |= (k < G.nlevels && max(slot0, G.t_kp_off[k]) < min(slot0 + kDescGroup, G.t_kp_off[k] + n[k])) ? 1 : 0;
+            any |= (k < G.nlevels && max(slot0, G.t_kp_off[k]) < min(slot0 + kGroup, G.t_kp_off[k] + n[k])) ? 1 : 0;
         if (!any) return;
     }
 
-    // lane j < kDescGroup: geometry of slot slot0 + j (invalid slots compute on pixel (19, 19) of
+    // lane j < kGroup: geometry of slot slot0 + j (invalid slots compute on pixel (19, 19) of
     // level 0 and store nothing); every table below is read with uniform, independent loads
     int my_l = 0, my_valid = 0, my_oi = 0, my_x = kEdge, my_y = kEdge, my_resp = 0;
     int my_pitch, my_off, my_patch, my_plane;
     float my_scale;
     {
-        const int slot = slot0 + (lane & (kDescGroup - 1));
+        const int slot = slot0 + (lane & (kGroup - 1));
         int l = 0;
 #pragma unroll
         for (int k = 1; k < ORBGPU_MAX_LEVELS; k++) l += slot >= G.t_kp_off[k] ? 1 : 0;  // unused levels hold INT_MAX
@@ -2040,7 +2042,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr
         my_plane = my_off - kEdge * my_pitch - kLeftMargin;  // the level's block: the blurred level is stored in tiles
         my_off += my_y * my_pitch + my_x;
     }
-    if (__ballot(my_valid && lane < kDescGroup) == 0) return;
+    if (__ballot(my_valid && lane < kGroup) == 0) return;
     ORB_DSTAMP(1);
     const uint8_t *fpyr = pyr + (int64_t)f * G.pyr_frame_bytes, *fblur = blur + (int64_t)f * G.pyr_frame_bytes;
 
@@ -2068,8 +2070,8 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr
         }
     }
     int my_m10 = 0, my_m01 = 0;
-#pragma unroll 4
-    for (int j = 0; j < kDescGroup; j++) {
+#pragma unroll 2
+    for (int j = 0; j < kGroup; j++) {
         const int pitch = __builtin_amdgcn_readlane(my_pitch, j), off = __builtin_amdgcn_readlane(my_off, j);
         const int sh = (off - 15) & 3;  // planes are 4-byte aligned: the alignment of x - 15 is that of its byte offset
         const uint8_t *c = fpyr + off - sh;
@@ -2093,7 +2095,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);
     float my_a, my_b;
     sincos_rounded(__fmul_rn(my_angle, factorPI), &my_b, &my_a);
-    if (lane < kDescGroup && my_valid) {
+    if (lane < kGroup && my_valid) {
         orbgpu_keypoint k;
         const float fx = (float)my_x, fy = (float)my_y;
         k.x = my_l ? __fmul_rn(fx, my_scale) : fx;
@@ -2147,11 +2149,11 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t *__restrict__ pyr
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { px0[k] = (float)pt[k].x; py0[k] = (float)pt[k].y; px1[k] = (float)pt[k].z; py1[k] = (float)pt[k].w; }
-    for (int j = 0; j < kDescGroup; j++) {
+    for (int j = 0; j < kGroup; j++) {
 #pragma unroll
         for (int m = 0; m < 6; m++) pw[srow[m] * (kBPitch / 4) + scol[m]] = pre[m];
         const int ox = (__builtin_amdgcn_readlane(my_off, j) - kBR) & 3;
-        if (j + 1 < kDescGroup) patch_loads(j + 1, pre);
+        if (j + 1 < kGroup) patch_loads(j + 1, pre);
         __builtin_amdgcn_wave_barrier();
         const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_a), j));
         const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_b), j));
@@ -2279,7 +2281,8 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
     if (tune.fast_queue_cap >= 1 && tune.fast_queue_cap < qcap) qcap = tune.fast_queue_cap;
     const size_t lds = (size_t)queue_off + (size_t)qcap * 2;
     // A batch: one wave per workgroup and runs of cells, so that a CU holds as many independent workgroups as its
-    // LDS allows; a few frames: the cells spread over all CUs, two waves on each
+    // LDS allows; a few frames: the cells spread over all CUs, four waves on each (a single 640 x 480 frame: 8.6 us
+    // with two waves per cell, 7.2 with four; eight made the whole call 2 us slower than four)
     const bool batch = (int64_t)G.total_cells * nimg >= 16384;
     const int per_wg = batch ? kFastQuad : 1;
     const dim3 grid((G.total_cells + per_wg - 1) / per_wg, nimg);
@@ -2288,10 +2291,10 @@ int launch_fast(hipStream_t st, int nimg, const uint8_t *pyr, const Geom &G, con
                        score_pitch, queue_off, qcap)
     if (kTP == kTPNarrow) {
         if (batch) ORB_FAST_LAUNCH(kTPNarrow, 64);
-        else ORB_FAST_LAUNCH(kTPNarrow, 128);
+        else ORB_FAST_LAUNCH(kTPNarrow, 256);
     } else {
         if (batch) ORB_FAST_LAUNCH(kTPWide, 64);
-        else ORB_FAST_LAUNCH(kTPWide, 128);
+        else ORB_FAST_LAUNCH(kTPWide, 256);
     }
 #undef ORB_FAST_LAUNCH
     ORBGPU_HIP_CHECK(hipGetLastError());
@@ -2399,9 +2402,12 @@ int launch_describe(hipStream_t st, int nimg, const uint8_t *pyr, const uint8_t 
 {
     Geom G = G_;
     G.nimg = nimg;
-    hipLaunchKernelGGL(k_describe, frame_grid((G.total_kp_cap + 1 * kDescGroup - 1) / (1 * kDescGroup), nimg), dim3(64), 0, st, pyr,
-                       blur, G, sel, sel_count,
-                       pattern, kps, desc, counts, capacity, status);
+    if (nimg <= 2)
+        hipLaunchKernelGGL(k_describe<kDescGroupFew>, frame_grid((G.total_kp_cap + kDescGroupFew - 1) / kDescGroupFew, nimg), dim3(64), 0, st,
+                           pyr, blur, G, sel, sel_count, pattern, kps, desc, counts, capacity, status);
+    else
+        hipLaunchKernelGGL(k_describe<kDescGroup>, frame_grid((G.total_kp_cap + kDescGroup - 1) / kDescGroup, nimg), dim3(64), 0, st, pyr, blur,
+                           G, sel, sel_count, pattern, kps, desc, counts, capacity, status);
     ORBGPU_HIP_CHECK(hipGetLastError());
     return ORBGPU_OK;
 }
