@@ -1869,8 +1869,8 @@ __global__ __launch_bounds__(kBlurThreads) void k_blur(const uint8_t *__restrict
     blur_tile(pyr, blur, G, f, tile_tab[t], hpair, threadIdx.x, true);
 }
 
-// One or two frames: the quadtree's few long workgroups (blockIdx.x < levels) and the blur's tiles (sixteen per
-// workgroup, a wave each, in the dynamic LDS) in one launch.  Both depend on the pyramid and FAST only; as two
+// One or two frames: the quadtree's few long workgroups (blockIdx.x < levels) and the blur's tiles (one per wave of
+// a workgroup, in the dynamic LDS) in one launch.  Both depend on the pyramid and FAST only; as two
 // launches on one stream the blur's few microseconds come on top of the quadtree's, and a second stream costs
 // more than that in hand-overs.
 __global__ __launch_bounds__(1024) void k_octree_blur(OCTREE_ARGS, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
@@ -1883,7 +1883,7 @@ __global__ __launch_bounds__(1024) void k_octree_blur(OCTREE_ARGS, const uint8_t
     }
     extern __shared__ __align__(16) unsigned char dyn_lds_blur[];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = ((int)blockIdx.x - G.nlevels) * 16 + wv;
+    const int t = ((int)blockIdx.x - G.nlevels) * (int)(blockDim.x >> 6) + wv;
     uint32_t *hpair = reinterpret_cast<uint32_t *>(dyn_lds_blur) + wv * kBlurLdsWords;
     blur_tile(pyr, blur, G, blockIdx.y, t < ntiles ? tile_tab[t] : 0u, hpair, threadIdx.x & 63, t < ntiles);
 }
@@ -2315,7 +2315,8 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
     const int lds_nodes = keys_cap && (size_t)keys_cap * 8 + node_bytes <= 56 * 1024;
     // one frame: few large workgroups (latency); a batch: many small ones so every CU holds several
     const bool batch = nimg * G.nlevels >= 256;
-    int threads = !batch ? 1024 : maxcap <= 512 ? 128 : nimg * G.nlevels >= 2048 ? 256 : 512;
+    // (one frame of 640 x 480 at 1000 features: 512 threads make the call 2.7 us shorter than 1024, 256 are no better than 1024)
+    int threads = !batch ? (maxcap <= 512 ? 512 : 1024) : maxcap <= 512 ? 128 : nimg * G.nlevels >= 2048 ? 256 : 512;
     if (tune.oct_threads) threads = tune.oct_threads;  // measurement hook
     const size_t coff_off = (size_t)keys_cap * 8 + (lds_nodes ? node_bytes : 0);
     size_t dyn = coff_off + (size_t)((threads > kMaxRoots ? threads : kMaxRoots) + 1) * 4;
@@ -2339,9 +2340,10 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
         pts_cap &= ~3;
         if (pts_cap < 256) pts_cap = 0;
         if (pts_cap) dyn = pts_off + (size_t)pts_cap * 8;
-        // one or two frames: the blur's tiles ride in the same launch (sixteen waves per workgroup, a tile's LDS each)
-        bool fuse_blur = with_blur && blur_done && threads == 1024 && with_blur->ntiles > 0;
-        const size_t blur_lds = (size_t)16 * kBlurLdsWords * 4;
+        // one or two frames: the blur's tiles ride in the same launch (a tile and its LDS per wave of a workgroup)
+        bool fuse_blur = with_blur && blur_done && with_blur->ntiles > 0;
+        const int nwaves = threads / 64;
+        const size_t blur_lds = (size_t)nwaves * kBlurLdsWords * 4;
         if (fuse_blur && blur_lds > dyn) dyn = blur_lds;
         // dynamic LDS beyond 64 KiB is asked for once per device and kernel (the attribute belongs to the device's copy
         // of the kernel); handles on several devices, or the two extractors of a stereo build on two host threads, may
@@ -2364,7 +2366,7 @@ int launch_octree(hipStream_t st, int nimg, const Geom &G, const uint32_t *slots
             }
         }
         if (fuse_blur) {
-            hipLaunchKernelGGL(k_octree_blur, dim3(G.nlevels + (with_blur->ntiles + 15) / 16, nimg), dim3(threads), dyn, st, G, slots, cell_counts,
+            hipLaunchKernelGGL(k_octree_blur, dim3(G.nlevels + (with_blur->ntiles + nwaves - 1) / nwaves, nimg), dim3(threads), dyn, st, G, slots, cell_counts,
                                cand, nodes, scratch, sel, sel_count, cand_count, status, keys_cap, lds_nodes, (int)coff_off, pts_cap, (int)pts_off,
                                with_blur->pyr, with_blur->blur, with_blur->tile_tab, with_blur->ntiles);
             *blur_done = true;
