@@ -38,6 +38,10 @@ struct MatchArgs {
     // a grid built earlier with the same t_cap and build origin (one pair): cell_start [3080] | grid records
     // [4*t_cap] | grid descriptors [8*t_cap]; null: the call builds the grid in its scratch
     const int32_t *grid;
+    // grid built by the call: keep only train keypoints of octave < grid_levels (0: all).  SearchForInitialization
+    // asks GetFeaturesInArea for level 0 alone (src/ORBmatcher.cc:448-452), so the other levels' keypoints -- four
+    // fifths of a window's entries -- need not enter its grid; their order among themselves is unchanged.
+    int32_t grid_levels;
     const uint8_t *occupied;
     int32_t *assign;   // [pair][t_cap]
     int32_t *qmatch;   // [pair][q_cap] or null

@@ -385,6 +385,7 @@ static int run_window(orbgpu_matcher *m, int32_t mode, int32_t npairs, const orb
     A.th_dist = th_dist; A.nnratio = nnratio; A.check_orientation = ori; A.nmatches = d_nmatches;
     A.seg_start = d_seg_start; A.seg_index = d_seg_index;
     A.grid = npairs == 1 ? d_grid : nullptr;
+    A.grid_levels = (mode == 3 && !A.grid) ? 1 : 0;  // SearchForInitialization looks at level 0 only
     if ((rc = m->stats.ensure((size_t)npairs * 16))) return rc;
     ORBGPU_HIP_CHECK(hipMemsetAsync(m->stats.p, 0, (size_t)npairs * 16, m->stream));
     A.stats = (int32_t *)m->stats.p;

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
     for (int i = tid; i < n2; i += nt_) {
         const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.gminX), P.invW));
         const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.gminY), P.invH));
-        if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS) atomicAdd(&cs[px * ORBGPU_GRID_ROWS + py], 1);
+        if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS && (A.grid_levels == 0 || P.K2[i].octave < A.grid_levels))
+            atomicAdd(&cs[px * ORBGPU_GRID_ROWS + py], 1);
     }
     __syncthreads();
     {
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(1024) void k_grid_build(MatchArgs A)
         for (int i = tid; i < n2; i += nt_) {
             const int px = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].x, A.gminX), P.invW));
             const int py = (int)roundf(__fmul_rn(__fsub_rn(P.K2[i].y, A.gminY), P.invH));
-            if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS) {
+            if (px >= 0 && px < ORBGPU_GRID_COLS && py >= 0 && py < ORBGPU_GRID_ROWS && (A.grid_levels == 0 || P.K2[i].octave < A.grid_levels)) {
                 const int cidx = px * ORBGPU_GRID_ROWS + py;
                 gidx[cs[cidx] + atomicAdd(&cursor[cidx], 1)] = i;
             }
