@@ -1386,6 +1386,12 @@ __device__ __forceinline__ void octree_level(const int level, const int f, const
         M += total;
     }
     OCT_T(1);
+    if (M >= (1 << 21)) {
+        // the quadrant populations travel in 21-bit fields (pack_kids): a level with two million candidates or more
+        // (a 4127 x 4127 level of isolated dots) is reported, not mis-counted
+        if (tid == 0) atomicOr(status, 1);
+        M = (1 << 21) - 1;
+    }
     if (tid == 0) cand_count[f * G.nlevels + level] = M;
     if (M == 0) {
         if (tid == 0) *out_count = 0;
